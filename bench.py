@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Headline benchmark: encode+decode GB/s (int16 in) and compression ratio.
+
+One *step* = one pass of the hot path over one batch: encode the whole batch of
+chunks, then decode it, inputs and outputs resident in HBM.  Default workload is
+BASELINE.json configs[1]: 1M x 7000 int16 Gaussian(sigma=10), m=8, framed as 500
+HDF5 chunks of 2000 x 7000 (the reference's Nab chunk shape, docs/Performance.md:16).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: weak scaling -- every rank encodes/decodes its own 1M-waveform shard on its own
+GPU; the only collective is the all-gather of encoded sizes (deltarice_amd/dist.py).
+
+Rank 0 prints ONE JSON line.  `roofline` is for the decode kernel (north_star's
+target): algorithmic bytes = 2*(1+ratio) per sample over the kernel's mean duration
+measured with HIP events on the codec's stream.  `cpu_baseline` times the reference's
+own filter (oracle/_ref, built from src/deltaRice.c) -- or this repo's port of it when
+that library is absent -- on a bounded sample of the same workload on the host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--waves", type=int, default=1_000_000, help="waveforms per GPU")
+    ap.add_argument("--wave-len", type=int, default=7000)
+    ap.add_argument("--chunk-waves", type=int, default=2000, help="waveforms per HDF5 chunk")
+    ap.add_argument("--m", type=int, default=8, help="RiceParameter")
+    ap.add_argument("--dist", choices=["gauss", "ar1"], default="gauss")
+    ap.add_argument("--decode-impl", type=int, default=1)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0: skip)")
+    ap.add_argument("--seed", type=int, default=1234)
+    return ap.parse_args()
+
+
+def synth(device, n_waves, L, kind, seed):
+    """Synthetic batch generated in HBM (never crosses PCIe)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    out = torch.empty(n_waves * L, dtype=torch.int16, device=device)
+    slab = max(1, min(n_waves, (1 << 28) // L))  # ~1 GiB of float32 per slab
+    for w0 in range(0, n_waves, slab):
+        w1 = min(n_waves, w0 + slab)
+        if kind == "gauss":
+            # README.md:82: normal(0, 10).astype(int16) (truncation toward zero)
+            v = torch.randn((w1 - w0) * L, device=device, generator=g).mul_(10.0).to(torch.int16)
+            out[w0 * L:w1 * L] = v
+        else:
+            # AR(1) rho=0.95, marginal sigma=32, stationary start, round to nearest
+            rho, sigma = 0.95, 32.0
+            e = torch.randn((w1 - w0, L), device=device, generator=g).mul_(sigma * (1 - rho * rho) ** 0.5)
+            x = torch.randn(w1 - w0, device=device, generator=g).mul_(sigma)
+            e[:, 0] = x
+            for t in range(1, L):
+                e[:, t].add_(e[:, t - 1], alpha=rho)
+            out[w0 * L:w1 * L] = torch.round(e).to(torch.int16).reshape(-1)
+    return out
+
+
+def cpu_baseline(x_host_chunks, opts, budget_s):
+    """Times the CPU filter on whole chunks until the budget is spent; GB/s of raw bytes
+    over encode+decode time."""
+    from oracle import oracle as O
+    use_ref = O.have_ref("omp")
+    t_enc = t_dec = 0.0
+    done = 0
+    raw = 0
+    t_start = time.perf_counter()
+    for xc in x_host_chunks:
+        if use_ref:
+            t0 = time.perf_counter(); enc = O.ref_filter(xc, opts, False); t1 = time.perf_counter()
+            t2 = time.perf_counter(); dec = O.ref_filter(enc, opts, True); t3 = time.perf_counter()
+            ok = dec == xc.tobytes()
+        else:
+            t0 = time.perf_counter(); w = O.encode_chunk(xc, opts); t1 = time.perf_counter()
+            t2 = time.perf_counter(); y = O.decode_chunk(w, opts, fast=True); t3 = time.perf_counter()
+            ok = np.array_equal(y, xc.reshape(-1))
+        assert ok, "cpu baseline round trip failed"
+        t_enc += t1 - t0
+        t_dec += t3 - t2
+        raw += xc.nbytes
+        done += 1
+        if time.perf_counter() - t_start > budget_s:
+            break
+    cores = int(os.environ.get("OMP_NUM_THREADS", 0)) or O.num_threads()
+    return {
+        "value": raw / (t_enc + t_dec) / 1e9, "unit": "GB/s", "cores": cores,
+        "kind": "reference" if use_ref else "port",
+        "encode_GBps": raw / t_enc / 1e9, "decode_GBps": raw / t_dec / 1e9,
+        "sample": f"{done} chunks of the bench workload ({raw / 1e6:.0f} MB raw), "
+                  f"{'H5Z_filter_deltarice of src/deltaRice.c (OpenMP build, ctypes copies included)' if use_ref else 'oracle/deltarice_oracle.c (OpenMP)'}",
+    }
+
+
+def main():
+    a = parse_args()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    import deltarice_amd as dr
+    from deltarice_amd import dist as drdist
+
+    ctx = dr.Context(local)
+    ctx.set_option("decode_impl", a.decode_impl)
+    ctx.set_option("profile", 1)
+    dev = ctx.device
+    L, W = a.wave_len, a.chunk_waves
+    n_waves = (a.waves // W) * W
+    n_chunks = n_waves // W
+    opts = (a.m, L)
+    x = synth(dev, n_waves, L, a.dist, a.seed + rank)
+    torch.cuda.synchronize(dev)
+    plan = ctx.plan_uniform(n_chunks, W * L, opts)
+    words = torch.empty(plan.max_encoded_words, dtype=torch.int32, device=dev)
+    off = torch.empty(n_chunks + 1, dtype=torch.int64, device=dev)
+    y = torch.empty_like(x)
+    raw_bytes = x.numel() * 2
+
+    def step(collect=None):
+        plan.encode_async(x, words, off)
+        if collect is not None:
+            collect["enc"].append(plan.last_timings())
+        if world > 1:
+            with torch.cuda.stream(ctx.stream):
+                drdist.gather_encoded_sizes(off[-1])
+        plan.decode_async(words, off, y)
+        if collect is not None:
+            collect["dec"].append(plan.last_timings())
+
+    for _ in range(a.warmup):
+        step()
+    total_words = plan.finish()
+    assert torch.equal(x, y), "round trip failed"  # gating, not timed
+    ratio = total_words * 4 / raw_bytes
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # --- timed region: EXACTLY K steps, launch only, no host sync inside -------------
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    ctx.stream.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    plan.finish()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # --- per-kernel durations (HIP events on the codec's stream), outside the timed region
+    coll = {"enc": [], "dec": []}
+    for _ in range(max(3, min(a.steps, 10))):
+        step(coll)
+        ctx.stream.synchronize()
+    enc_ms = np.median(np.array(coll["enc"]), axis=0)
+    dec_ms = np.median(np.array(coll["dec"]), axis=0)
+    dec_kernel_ms = float(np.mean(np.array(coll["dec"])[:, 1]))
+    algo_bytes = 2.0 * (1.0 + ratio) * x.numel()  # read 2*ratio + write 2 (decode), per sample
+    achieved = algo_bytes / (dec_kernel_ms * 1e-3) / 1e9
+    pack_ms = float(np.mean(np.array(coll["enc"])[:, 2]))
+
+    if rank == 0:
+        res = {
+            "metric": "encode+decode GB/s (int16 in)",
+            "value": world * raw_bytes * a.steps / dt / 1e9,
+            "unit": "GB/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int16", "data": "synthetic",
+            "config": {"workload": f"{n_waves}x{L} int16 {'Gaussian(sigma=10)' if a.dist == 'gauss' else 'AR(1) rho=0.95 sigma=32'}, "
+                                   f"m={a.m}, {n_chunks} chunks of {W}x{L} per GPU, encode then decode, HBM resident",
+                       "waveforms_per_gpu": n_waves, "wave_len": L, "rice_m": a.m, "chunks_per_gpu": n_chunks,
+                       "decode_impl": a.decode_impl},
+            "compression_ratio": ratio,
+            "encode_GBps": raw_bytes / (enc_ms[3] * 1e-3) / 1e9,
+            "decode_GBps": raw_bytes / (dec_ms[3] * 1e-3) / 1e9,
+            "kernel_ms": {"encode_sizes": float(enc_ms[0]), "encode_scan": float(enc_ms[1]), "encode_pack": float(enc_ms[2]),
+                          "decode_walk": float(dec_ms[0]), "decode_kernel": float(dec_ms[1])},
+            "roofline": {"bound": "hbm", "kernel": "k_decode_lanes", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": dec_kernel_ms},
+            "roofline_encode": {"bound": "hbm", "kernel": "k_encode_pack", "achieved": algo_bytes / (pack_ms * 1e-3) / 1e9,
+                                "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                "frac": algo_bytes / (pack_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel_ms": pack_ms},
+        }
+        if world == 1 and a.cpu_seconds > 0:
+            nsamp = min(n_chunks, 64)
+            chunks = [x[c * W * L:(c + 1) * W * L].cpu().numpy() for c in range(nsamp)]
+            res["cpu_baseline"] = cpu_baseline(chunks, opts, a.cpu_seconds)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,430 @@
+// drx_api.hip -- C ABI (include/deltarice_hip.h) over the gfx950 kernels.
+//
+// Host-side glue only: option parsing, batch geometry, workspace ownership, launches.
+// There is deliberately no CPU implementation of the codec here: every entry point
+// either runs the HIP kernels or returns an error.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/deltarice_hip.h"
+#include "drx_internal.h"
+
+using namespace drx;
+
+struct drx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int decode_impl = 1;  // 0 simple, 1 staged <64,64>, 2 <64,32>, 3 <128,64>
+    int profile = 0;      // bracket kernels with HIP events (drx_plan_last_timings)
+    std::string last_error;
+    // scratch of the one-chunk host path (drx_filter_chunk_host), grown on demand
+    void *d_raw = nullptr;   size_t raw_cap = 0;
+    void *d_enc = nullptr;   size_t enc_cap = 0;
+    uint64_t *d_off = nullptr;
+    void *h_pin = nullptr;   size_t pin_cap = 0;
+    std::mutex mu;
+};
+
+struct drx_plan {
+    drx_ctx *ctx = nullptr;
+    Geom G{};
+    uint64_t total_samples = 0;
+    uint64_t max_words = 0;
+    ChunkDesc *d_chunks = nullptr;
+    uint32_t *d_wave_words = nullptr;  // n_i
+    uint32_t *d_wave_rel = nullptr;    // encode: header position relative to chunk start
+    uint64_t *d_wave_off = nullptr;    // decode: absolute header position
+    uint64_t *d_chunk_words = nullptr;
+    DevStatus *d_status = nullptr;
+    DevStatus *h_status = nullptr;  // pinned
+    bool last_was_encode = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+};
+
+static drx_status fail(drx_ctx *ctx, drx_status st, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->last_error = buf;
+    return st;
+}
+
+#define DRX_HIP(ctx, expr)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail((ctx), DRX_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" {
+
+const char *drx_version(void) { return "deltarice-hip 0.1 (gfx950)"; }
+
+const char *drx_status_str(drx_status s) {
+    switch (s) {
+        case DRX_OK: return "ok";
+        case DRX_ERR_ARG: return "invalid argument or compression_opts";
+        case DRX_ERR_DEVICE: return "HIP device/runtime error";
+        case DRX_ERR_CAPACITY: return "output capacity too small";
+        case DRX_ERR_CORRUPT: return "corrupt encoded chunk";
+        case DRX_ERR_UNSUPPORTED: return "not supported on the device path";
+        case DRX_ERR_NOMEM: return "out of memory";
+    }
+    return "unknown";
+}
+
+int drx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// cd_values -> options; the meaning of each slot is the reference's (src/deltaRice.c:248-291).
+drx_status drx_parse_cd_values(size_t cd_nelmts, const unsigned *cd_values, drx_opts *out) {
+    if (!out || (cd_nelmts && !cd_values)) return DRX_ERR_ARG;
+    long long m = 8;
+    out->wave_len = -1;
+    out->n_taps = 2;
+    memset(out->taps, 0, sizeof out->taps);
+    out->taps[0] = 1;
+    out->taps[1] = -1;
+    if (cd_nelmts >= 1) m = (int)cd_values[0];
+    if (cd_nelmts >= 2) out->wave_len = (int)cd_values[1];
+    if (cd_nelmts >= 3) {
+        const long long nt = (int)cd_values[2];
+        if (nt <= 0 || nt > DRX_MAX_TAPS || (size_t)nt + 3 > cd_nelmts) return DRX_ERR_ARG;
+        out->n_taps = (uint32_t)nt;
+        for (long long j = 0; j < nt; ++j) out->taps[j] = (int)cd_values[3 + j];
+        if (out->taps[0] == 0) return DRX_ERR_ARG;
+    }
+    // M must be a power of two (src/deltaRice.c:114-136); 1 <= M <= 32768 is the range in
+    // which the reference itself is well defined.
+    if (m <= 0 || (m & (m - 1)) != 0 || m > 32768) return DRX_ERR_ARG;
+    uint32_t k = 0;
+    while ((1ll << k) != m) ++k;
+    out->rice_k = k;
+    if (out->wave_len == 0 || out->wave_len < -1) return DRX_ERR_ARG;
+    return DRX_OK;
+}
+
+drx_status drx_ctx_create(int device, void *hip_stream, drx_ctx **out) {
+    if (!out) return DRX_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return DRX_ERR_DEVICE;
+    drx_ctx *c = new (std::nothrow) drx_ctx;
+    if (!c) return DRX_ERR_NOMEM;
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete c; return DRX_ERR_DEVICE; }
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return DRX_ERR_DEVICE; }
+        c->own_stream = true;
+    }
+    *out = c;
+    return DRX_OK;
+}
+
+void drx_ctx_destroy(drx_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->d_raw) (void)hipFree(c->d_raw);
+    if (c->d_enc) (void)hipFree(c->d_enc);
+    if (c->d_off) (void)hipFree(c->d_off);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+drx_status drx_ctx_synchronize(drx_ctx *c) {
+    if (!c) return DRX_ERR_ARG;
+    DRX_HIP(c, hipStreamSynchronize(c->stream));
+    return DRX_OK;
+}
+
+const char *drx_ctx_last_error(const drx_ctx *c) { return c ? c->last_error.c_str() : ""; }
+void *drx_ctx_stream(const drx_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+drx_status drx_ctx_set_option(drx_ctx *c, const char *key, int64_t value) {
+    if (!c || !key) return DRX_ERR_ARG;
+    if (!strcmp(key, "decode_impl")) {
+        if (value < 0 || value > 3) return DRX_ERR_ARG;
+        c->decode_impl = (int)value;
+        return DRX_OK;
+    }
+    if (!strcmp(key, "profile")) {
+        c->profile = value != 0;
+        return DRX_OK;
+    }
+    return DRX_ERR_ARG;
+}
+
+static void plan_free(drx_plan *p) {
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
+    if (p->d_chunks) (void)hipFree(p->d_chunks);
+    if (p->d_wave_words) (void)hipFree(p->d_wave_words);
+    if (p->d_wave_rel) (void)hipFree(p->d_wave_rel);
+    if (p->d_wave_off) (void)hipFree(p->d_wave_off);
+    if (p->d_chunk_words) (void)hipFree(p->d_chunk_words);
+    if (p->d_status) (void)hipFree(p->d_status);
+    if (p->h_status) (void)hipHostFree(p->h_status);
+    for (hipEvent_t e : p->ev) if (e) (void)hipEventDestroy(e);
+    delete p;
+}
+
+static drx_status plan_alloc(drx_ctx *ctx, drx_plan *p) {
+    DRX_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t W = p->G.total_waves ? p->G.total_waves : 1;
+    DRX_HIP(ctx, hipMalloc((void **)&p->d_wave_words, W * sizeof(uint32_t)));
+    DRX_HIP(ctx, hipMalloc((void **)&p->d_wave_rel, W * sizeof(uint32_t)));
+    DRX_HIP(ctx, hipMalloc((void **)&p->d_wave_off, W * sizeof(uint64_t)));
+    DRX_HIP(ctx, hipMalloc((void **)&p->d_chunk_words, (p->G.n_chunks + 1) * sizeof(uint64_t)));
+    DRX_HIP(ctx, hipMalloc((void **)&p->d_status, sizeof(DevStatus)));
+    DRX_HIP(ctx, hipHostMalloc((void **)&p->h_status, sizeof(DevStatus), hipHostMallocDefault));
+    memset(p->h_status, 0, sizeof(DevStatus));
+    for (hipEvent_t &e : p->ev) DRX_HIP(ctx, hipEventCreate(&e));
+    return DRX_OK;
+}
+
+drx_status drx_plan_create(drx_ctx *ctx, uint64_t n_chunks, const uint32_t *chunk_samples,
+                           const uint32_t *chunk_wave_len, uint32_t rice_k, drx_plan **out) {
+    if (!ctx || !out || !n_chunks || !chunk_samples || !chunk_wave_len) return DRX_ERR_ARG;
+    *out = nullptr;
+    if (rice_k > 15) return fail(ctx, DRX_ERR_ARG, "rice_k %u out of range 0..15", rice_k);
+    if (n_chunks > 0xffffffffull) return fail(ctx, DRX_ERR_ARG, "too many chunks");
+    std::vector<ChunkDesc> desc(n_chunks);
+    uint64_t soff = 0, wbase = 0, maxw = 0;
+    bool uniform = true;
+    for (uint64_t c = 0; c < n_chunks; ++c) {
+        const uint32_t N = chunk_samples[c];
+        // one chunk holds < 2^31 samples (int totalNumber, src/deltaRice.c:389)
+        if (N == 0 || N > 0x7fffffffu) return fail(ctx, DRX_ERR_ARG, "chunk %llu: bad sample count %u", (unsigned long long)c, N);
+        uint32_t L = chunk_wave_len[c] ? chunk_wave_len[c] : N;
+        if (L > 0x7fffffffu) return fail(ctx, DRX_ERR_ARG, "chunk %llu: bad waveform length", (unsigned long long)c);
+        const uint32_t W = (uint32_t)(((uint64_t)N + L - 1) / L);
+        desc[c] = ChunkDesc{soff, wbase, N, L, W, 0};
+        if (N != chunk_samples[0] || L != (chunk_wave_len[0] ? chunk_wave_len[0] : chunk_samples[0])) uniform = false;
+        soff += N;
+        wbase += W;
+        // 25 bits per sample worst case, rounded up per waveform, + headers
+        maxw += 1 + W + (((uint64_t)N * 25u + 31u) >> 5) + W;
+    }
+    drx_plan *p = new (std::nothrow) drx_plan;
+    if (!p) return DRX_ERR_NOMEM;
+    p->ctx = ctx;
+    p->total_samples = soff;
+    p->max_words = maxw;
+    p->G.n_chunks = n_chunks;
+    p->G.total_waves = wbase;
+    p->G.uniform = uniform ? 1u : 0u;
+    p->G.u_n_samples = desc[0].n_samples;
+    p->G.u_wave_len = desc[0].wave_len;
+    p->G.u_n_waves = desc[0].n_waves;
+    p->G.k = rice_k;
+    drx_status st = plan_alloc(ctx, p);
+    if (st == DRX_OK && !uniform) {
+        hipError_t e = hipMalloc((void **)&p->d_chunks, n_chunks * sizeof(ChunkDesc));
+        if (e == hipSuccess) e = hipMemcpy(p->d_chunks, desc.data(), n_chunks * sizeof(ChunkDesc), hipMemcpyHostToDevice);
+        if (e != hipSuccess) st = fail(ctx, DRX_ERR_DEVICE, "chunk table upload failed: %s", hipGetErrorString(e));
+    }
+    if (st != DRX_OK) { plan_free(p); return st; }
+    p->G.chunks = p->d_chunks;
+    *out = p;
+    return DRX_OK;
+}
+
+drx_status drx_plan_create_uniform(drx_ctx *ctx, uint64_t n_chunks, uint32_t chunk_samples,
+                                   uint32_t wave_len, uint32_t rice_k, drx_plan **out) {
+    if (!ctx || !out || !n_chunks) return DRX_ERR_ARG;
+    *out = nullptr;
+    if (rice_k > 15) return fail(ctx, DRX_ERR_ARG, "rice_k %u out of range 0..15", rice_k);
+    if (chunk_samples == 0 || chunk_samples > 0x7fffffffu) return fail(ctx, DRX_ERR_ARG, "bad chunk sample count");
+    if (n_chunks > 0xffffffffull) return fail(ctx, DRX_ERR_ARG, "too many chunks");
+    const uint32_t L = wave_len ? wave_len : chunk_samples;
+    if (L > 0x7fffffffu) return fail(ctx, DRX_ERR_ARG, "bad waveform length");
+    const uint32_t W = (uint32_t)(((uint64_t)chunk_samples + L - 1) / L);
+    drx_plan *p = new (std::nothrow) drx_plan;
+    if (!p) return DRX_ERR_NOMEM;
+    p->ctx = ctx;
+    p->total_samples = n_chunks * chunk_samples;
+    p->max_words = n_chunks * (1 + 2ull * W + (((uint64_t)chunk_samples * 25u + 31u) >> 5));
+    p->G.chunks = nullptr;
+    p->G.n_chunks = n_chunks;
+    p->G.total_waves = n_chunks * W;
+    p->G.uniform = 1;
+    p->G.u_n_samples = chunk_samples;
+    p->G.u_wave_len = L;
+    p->G.u_n_waves = W;
+    p->G.k = rice_k;
+    drx_status st = plan_alloc(ctx, p);
+    if (st != DRX_OK) { plan_free(p); return st; }
+    *out = p;
+    return DRX_OK;
+}
+
+void drx_plan_destroy(drx_plan *p) { plan_free(p); }
+uint64_t drx_plan_n_chunks(const drx_plan *p) { return p ? p->G.n_chunks : 0; }
+uint64_t drx_plan_total_samples(const drx_plan *p) { return p ? p->total_samples : 0; }
+uint64_t drx_plan_total_waves(const drx_plan *p) { return p ? p->G.total_waves : 0; }
+uint64_t drx_plan_max_encoded_words(const drx_plan *p) { return p ? p->max_words : 0; }
+const uint32_t *drx_plan_wave_words(const drx_plan *p) { return p ? p->d_wave_words : nullptr; }
+const uint64_t *drx_plan_wave_word_off(const drx_plan *p) { return p ? p->d_wave_off : nullptr; }
+
+drx_status drx_plan_read_wave_words(drx_plan *p, uint32_t *host_out) {
+    if (!p || !host_out) return DRX_ERR_ARG;
+    drx_ctx *ctx = p->ctx;
+    DRX_HIP(ctx, hipSetDevice(ctx->device));
+    DRX_HIP(ctx, hipMemcpyAsync(host_out, p->d_wave_words, p->G.total_waves * sizeof(uint32_t),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    DRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DRX_OK;
+}
+
+drx_status drx_encode(drx_plan *p, const int16_t *d_in, uint32_t *d_out, uint64_t out_cap_words,
+                      uint64_t *d_chunk_word_off) {
+    if (!p || !d_in || !d_out || !d_chunk_word_off) return DRX_ERR_ARG;
+    drx_ctx *ctx = p->ctx;
+    DRX_HIP(ctx, hipSetDevice(ctx->device));
+    DRX_HIP(ctx, hipMemsetAsync(p->d_status, 0, sizeof(DevStatus), ctx->stream));
+    DRX_HIP(ctx, launch_encode(p->G, d_in, d_out, out_cap_words, d_chunk_word_off, p->d_wave_words,
+                               p->d_wave_rel, p->d_chunk_words, p->d_status, ctx->profile ? p->ev : nullptr,
+                               ctx->stream));
+    p->ev_valid = ctx->profile != 0;
+    p->last_was_encode = true;
+    return DRX_OK;
+}
+
+drx_status drx_decode(drx_plan *p, const uint32_t *d_in, uint64_t in_words,
+                      const uint64_t *d_chunk_word_off, int16_t *d_out) {
+    if (!p || !d_in || !d_chunk_word_off || !d_out) return DRX_ERR_ARG;
+    drx_ctx *ctx = p->ctx;
+    DRX_HIP(ctx, hipSetDevice(ctx->device));
+    DRX_HIP(ctx, hipMemsetAsync(p->d_status, 0, sizeof(DevStatus), ctx->stream));
+    DRX_HIP(ctx, launch_decode(p->G, d_in, in_words, d_chunk_word_off, d_out, p->d_wave_off,
+                               p->d_wave_words, p->d_status, ctx->decode_impl, ctx->profile ? p->ev : nullptr,
+                               ctx->stream));
+    p->ev_valid = ctx->profile != 0;
+    p->last_was_encode = false;
+    return DRX_OK;
+}
+
+drx_status drx_plan_last_timings(drx_plan *p, float ms[4]) {
+    if (!p || !ms) return DRX_ERR_ARG;
+    drx_ctx *ctx = p->ctx;
+    if (!p->ev_valid) return fail(ctx, DRX_ERR_ARG, "set the context option \"profile\" before the call to be timed");
+    DRX_HIP(ctx, hipSetDevice(ctx->device));
+    DRX_HIP(ctx, hipEventSynchronize(p->ev[3]));
+    for (int i = 0; i < 3; ++i) DRX_HIP(ctx, hipEventElapsedTime(&ms[i], p->ev[i], p->ev[i + 1]));
+    DRX_HIP(ctx, hipEventElapsedTime(&ms[3], p->ev[0], p->ev[3]));
+    return DRX_OK;
+}
+
+drx_status drx_plan_finish(drx_plan *p, uint64_t *total_words) {
+    if (!p) return DRX_ERR_ARG;
+    drx_ctx *ctx = p->ctx;
+    DRX_HIP(ctx, hipSetDevice(ctx->device));
+    DRX_HIP(ctx, hipMemcpyAsync(p->h_status, p->d_status, sizeof(DevStatus), hipMemcpyDeviceToHost, ctx->stream));
+    DRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (total_words) *total_words = p->h_status->total_words;
+    if (p->h_status->err & kErrCorrupt) return fail(ctx, DRX_ERR_CORRUPT, "encoded input failed header-chain validation");
+    if (p->h_status->err & kErrCapacity)
+        return fail(ctx, DRX_ERR_CAPACITY, "encoded batch needs %llu words", (unsigned long long)p->h_status->total_words);
+    return DRX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// one chunk through host memory: the body of the H5Z callback
+// ---------------------------------------------------------------------------
+static drx_status grow(drx_ctx *ctx, void **ptr, size_t *cap, size_t need, bool pinned) {
+    if (*cap >= need) return DRX_OK;
+    size_t want = need + need / 4 + 4096;
+    if (*ptr) { if (pinned) (void)hipHostFree(*ptr); else (void)hipFree(*ptr); *ptr = nullptr; *cap = 0; }
+    hipError_t e = pinned ? hipHostMalloc(ptr, want, hipHostMallocDefault) : hipMalloc(ptr, want);
+    if (e != hipSuccess) return fail(ctx, DRX_ERR_DEVICE, "allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
+    *cap = want;
+    return DRX_OK;
+}
+
+drx_status drx_filter_chunk_host(drx_ctx *ctx, int reverse, size_t cd_nelmts, const unsigned *cd_values,
+                                 const void *in, size_t nbytes, void **out, size_t *out_bytes) {
+    if (!ctx || !in || !out || !out_bytes) return DRX_ERR_ARG;
+    drx_opts o;
+    if (drx_parse_cd_values(cd_nelmts, cd_values, &o) != DRX_OK)
+        return fail(ctx, DRX_ERR_ARG, "invalid compression_opts");
+    if (!(o.n_taps == 2 && o.taps[0] == 1 && o.taps[1] == -1))
+        return fail(ctx, DRX_ERR_UNSUPPORTED, "prediction filters other than [1,-1] are not on the device path yet");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DRX_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->d_off) DRX_HIP(ctx, hipMalloc((void **)&ctx->d_off, 2 * sizeof(uint64_t)));
+
+    uint32_t n_samples;
+    if (!reverse) {
+        // nbytes must be a whole number of int16 (src/deltaRice.c:394-397) and < 2^31 samples (:389)
+        if (nbytes == 0 || (nbytes & 1u) || nbytes / 2 > 0x7fffffffull) return fail(ctx, DRX_ERR_ARG, "bad chunk size %zu", nbytes);
+        n_samples = (uint32_t)(nbytes / 2);
+    } else {
+        if (nbytes < 8 || (nbytes & 3u)) return fail(ctx, DRX_ERR_CORRUPT, "encoded chunk of %zu bytes", nbytes);
+        memcpy(&n_samples, in, 4);  // totalNumberPoints (:306)
+        if (n_samples == 0 || n_samples > 0x7fffffffu) return fail(ctx, DRX_ERR_CORRUPT, "bad sample count in header");
+    }
+    const uint32_t L = (o.wave_len < 0) ? 0u : (uint32_t)o.wave_len;
+    drx_plan *plan = nullptr;
+    drx_status st = drx_plan_create_uniform(ctx, 1, n_samples, L, o.rice_k, &plan);
+    if (st != DRX_OK) return st;
+    const size_t raw_bytes = (size_t)n_samples * 2;
+    const size_t enc_cap_bytes = (size_t)plan->max_words * 4;
+    void *result = nullptr;
+    do {
+        if ((st = grow(ctx, &ctx->d_raw, &ctx->raw_cap, raw_bytes, false)) != DRX_OK) break;
+        if ((st = grow(ctx, &ctx->d_enc, &ctx->enc_cap, reverse ? nbytes : enc_cap_bytes, false)) != DRX_OK) break;
+        hipError_t e;
+        if (!reverse) {
+            e = hipMemcpyAsync(ctx->d_raw, in, raw_bytes, hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) { st = fail(ctx, DRX_ERR_DEVICE, "H2D failed: %s", hipGetErrorString(e)); break; }
+            if ((st = drx_encode(plan, (const int16_t *)ctx->d_raw, (uint32_t *)ctx->d_enc, plan->max_words, ctx->d_off)) != DRX_OK) break;
+            uint64_t words = 0;
+            if ((st = drx_plan_finish(plan, &words)) != DRX_OK) break;
+            const size_t nb = (size_t)words * 4;
+            result = malloc(nb);
+            if (!result) { st = DRX_ERR_NOMEM; break; }
+            e = hipMemcpyAsync(result, ctx->d_enc, nb, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) { st = fail(ctx, DRX_ERR_DEVICE, "D2H failed: %s", hipGetErrorString(e)); break; }
+            *out_bytes = nb;
+        } else {
+            const uint64_t off[2] = {0, (uint64_t)(nbytes / 4)};
+            e = hipMemcpyAsync(ctx->d_enc, in, nbytes, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_off, off, sizeof off, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // `off` is a stack temporary
+            if (e != hipSuccess) { st = fail(ctx, DRX_ERR_DEVICE, "H2D failed: %s", hipGetErrorString(e)); break; }
+            if ((st = drx_decode(plan, (const uint32_t *)ctx->d_enc, nbytes / 4, ctx->d_off, (int16_t *)ctx->d_raw)) != DRX_OK) break;
+            if ((st = drx_plan_finish(plan, nullptr)) != DRX_OK) break;
+            result = malloc(raw_bytes);
+            if (!result) { st = DRX_ERR_NOMEM; break; }
+            e = hipMemcpyAsync(result, ctx->d_raw, raw_bytes, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) { st = fail(ctx, DRX_ERR_DEVICE, "D2H failed: %s", hipGetErrorString(e)); break; }
+            *out_bytes = raw_bytes;
+        }
+    } while (0);
+    drx_plan_destroy(plan);
+    if (st != DRX_OK) { free(result); return st; }
+    *out = result;
+    return DRX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,48 @@
+// drx_internal.h -- types shared by the kernels and the C ABI glue (not installed).
+#ifndef DRX_INTERNAL_H
+#define DRX_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace drx {
+
+// One HDF5 chunk of the batch (device resident table, ragged batches only).
+struct ChunkDesc {
+    uint64_t sample_off;  // first sample of the chunk in the raw int16 batch
+    uint64_t wave_base;   // global index of the chunk's first waveform
+    uint32_t n_samples;   // N  (u32 header word of the encoded chunk, src/deltaRice.c:415)
+    uint32_t wave_len;    // L  (>= 1; "whole chunk" already resolved to N)
+    uint32_t n_waves;     // ceil(N / L)
+    uint32_t pad_;
+};
+
+// Passed to kernels by value.
+struct Geom {
+    const ChunkDesc *chunks;  // device pointer, n_chunks entries (unused when uniform)
+    uint64_t n_chunks;
+    uint64_t total_waves;
+    uint32_t uniform;  // all chunks share (n_samples, wave_len): pure arithmetic mapping
+    uint32_t u_n_samples, u_wave_len, u_n_waves;
+    uint32_t k;  // log2(M)
+};
+
+struct DevStatus {
+    uint32_t err;  // kErr* bits, OR-ed by kernels
+    uint32_t pad_;
+    uint64_t total_words;  // encode: words of the encoded batch
+};
+
+constexpr uint32_t kErrCapacity = 1u;
+constexpr uint32_t kErrCorrupt = 2u;
+
+hipError_t launch_encode(const Geom &G, const int16_t *d_in, uint32_t *d_out, uint64_t out_cap,
+                         uint64_t *d_chunk_word_off, uint32_t *d_wave_words, uint32_t *d_wave_rel,
+                         uint64_t *d_chunk_words, DevStatus *d_status, hipEvent_t *ev, hipStream_t s);
+
+hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
+                         const uint64_t *d_chunk_word_off, int16_t *d_out, uint64_t *d_wave_off,
+                         uint32_t *d_wave_words, DevStatus *d_status, int impl, hipEvent_t *ev, hipStream_t s);
+
+}  // namespace drx
+#endif

@@ -1,0 +1,141 @@
+/*
+ * deltarice_hip.h -- C ABI of the MI355X (gfx950) Delta-Rice codec.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.
+ * It replaces the arithmetic of the reference's per-chunk filter
+ * (/root/reference/src/deltaRice.c) with HIP kernels; the HDF5-facing surface
+ * (H5Z_filter_deltarice, H5Z_DELTARICE, registration, plugin entry points) is
+ * declared in deltarice_h5filter.h and is a thin host wrapper over this file.
+ *
+ * Reference interface replaced by each entry point:
+ *   drx_parse_cd_values      parseCD_VALUES + determinePowerOf2  src/deltaRice.c:248-291,114-136
+ *   drx_encode               writeWholeCompressedByteString      src/deltaRice.c:383-441
+ *                            (perWaveCompression :365-381, encodeWaveform :49-63,
+ *                             compressWithRiceCoding :191-244), for a batch of chunks
+ *   drx_decode               readWholeCompressedByteString       src/deltaRice.c:301-341
+ *                            (perWaveDecompression :293-297, decompressWithRiceCoding
+ *                             :138-189, decodeWaveform :78-90), for a batch of chunks
+ *   drx_filter_chunk_host    the body of H5Z_filter_deltarice    src/deltaRice.c:468-490
+ *                            (host buffer in, malloc'ed host buffer out, one chunk)
+ *
+ * Data model.  A *batch* is a list of HDF5 chunks.  Chunk c holds n_samples[c]
+ * int16 samples cut into waveforms of wave_len[c] samples (the last one may be
+ * shorter, src/deltaRice.c:399-403).  Raw chunks lie back to back in one int16
+ * device buffer.  The encoded batch is one uint32 device buffer holding each
+ * chunk's filtered bytes exactly as the reference's filter would emit them
+ *   u32 n_samples | { u32 n_i | u32 payload_i[n_i] } per waveform
+ * plus a table chunk_word_off[n_chunks+1] of where each chunk starts (the role
+ * HDF5's chunk index plays in a file).
+ *
+ * All device pointers are on the context's device; every call is ordered on the
+ * context's stream and returns without waiting.  Errors found on the device
+ * (capacity, corrupt stream) are collected by drx_plan_finish().
+ * There is no CPU fallback anywhere behind this ABI.
+ */
+#ifndef DELTARICE_HIP_H
+#define DELTARICE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRX_FILTER_ID 32025 /* H5Z_FILTER_DELTARICE, src/deltaRice.h:7 */
+#define DRX_MAX_TAPS 64
+
+typedef struct drx_ctx drx_ctx;   /* one device + one stream + scratch */
+typedef struct drx_plan drx_plan; /* geometry of one batch, device resident */
+
+typedef enum {
+    DRX_OK = 0,
+    DRX_ERR_ARG = 1,         /* bad argument / compression_opts (reference: stderr + -1, :116-135,394-397) */
+    DRX_ERR_DEVICE = 2,      /* HIP runtime failure, or no usable GPU */
+    DRX_ERR_CAPACITY = 3,    /* encoded batch does not fit out_cap_words */
+    DRX_ERR_CORRUPT = 4,     /* encoded input fails validation (header chain, sizes) */
+    DRX_ERR_UNSUPPORTED = 5, /* valid for the reference, not (yet) on the device */
+    DRX_ERR_NOMEM = 6
+} drx_status;
+
+/* Parsed compression_opts = cd_values (src/deltaRice.c:248-291). */
+typedef struct {
+    uint32_t rice_k;   /* log2(RiceParameter), 0..15 */
+    int64_t wave_len;  /* WaveformLength; -1 = the whole chunk is one waveform */
+    uint32_t n_taps;   /* prediction filter; default 2 taps [1,-1] = delta */
+    int32_t taps[DRX_MAX_TAPS];
+} drx_opts;
+
+const char *drx_version(void);
+const char *drx_status_str(drx_status s);
+int drx_device_count(void);
+
+/* cd_values -> options.  Defaults: M=8, wave_len=-1, taps [1,-1]. */
+drx_status drx_parse_cd_values(size_t cd_nelmts, const unsigned *cd_values, drx_opts *out);
+
+/* hip_stream: a hipStream_t to borrow (e.g. the caller's), or NULL to create one. */
+drx_status drx_ctx_create(int device, void *hip_stream, drx_ctx **out);
+void drx_ctx_destroy(drx_ctx *ctx);
+drx_status drx_ctx_synchronize(drx_ctx *ctx);
+const char *drx_ctx_last_error(const drx_ctx *ctx);
+void *drx_ctx_stream(const drx_ctx *ctx);
+
+/* Plans.  chunk_wave_len[c] == 0 means "whole chunk" (WaveformLength = -1).
+ * Allocates the per-waveform tables on the device; no allocation happens in
+ * drx_encode / drx_decode. */
+drx_status drx_plan_create(drx_ctx *ctx, uint64_t n_chunks, const uint32_t *chunk_samples,
+                           const uint32_t *chunk_wave_len, uint32_t rice_k, drx_plan **out);
+drx_status drx_plan_create_uniform(drx_ctx *ctx, uint64_t n_chunks, uint32_t chunk_samples,
+                                   uint32_t wave_len, uint32_t rice_k, drx_plan **out);
+void drx_plan_destroy(drx_plan *plan);
+uint64_t drx_plan_n_chunks(const drx_plan *plan);
+uint64_t drx_plan_total_samples(const drx_plan *plan);
+uint64_t drx_plan_total_waves(const drx_plan *plan);
+/* Worst-case size of the encoded batch in uint32 words (25 bits per sample + headers). */
+uint64_t drx_plan_max_encoded_words(const drx_plan *plan);
+
+/* Encode.  d_in: int16[total_samples]; d_out: uint32[out_cap_words];
+ * d_chunk_word_off: uint64[n_chunks+1], written (word index of each chunk's first
+ * word in d_out; last entry = total words). */
+drx_status drx_encode(drx_plan *plan, const int16_t *d_in, uint32_t *d_out, uint64_t out_cap_words,
+                      uint64_t *d_chunk_word_off);
+
+/* Decode.  d_in: uint32[in_words]; d_chunk_word_off: uint64[n_chunks+1], read;
+ * d_out: int16[total_samples]. */
+drx_status drx_decode(drx_plan *plan, const uint32_t *d_in, uint64_t in_words,
+                      const uint64_t *d_chunk_word_off, int16_t *d_out);
+
+/* Waits for the plan's last encode/decode, reports device-side errors and (for
+ * encode) the number of words produced.  total_words may be NULL. */
+drx_status drx_plan_finish(drx_plan *plan, uint64_t *total_words);
+
+/* Device-side tables of the last call (valid until the next call on the plan):
+ * per-waveform payload word counts n_i and header word offsets.  For tests/tools. */
+const uint32_t *drx_plan_wave_words(const drx_plan *plan);
+const uint64_t *drx_plan_wave_word_off(const drx_plan *plan);
+/* Copies n_i of every waveform to host memory (waits for the stream). */
+drx_status drx_plan_read_wave_words(drx_plan *plan, uint32_t *host_out);
+
+/* One chunk, host memory, filter semantics (the H5Z callback body):
+ * reverse == 0: in = nbytes of int16 samples -> *out = filtered bytes
+ * reverse != 0: in = nbytes of filtered bytes -> *out = int16 samples
+ * *out is allocated with malloc() (HDF5's allocator for filter buffers,
+ * src/deltaRice.c:412,434); the caller owns it.  `in` is not freed. */
+drx_status drx_filter_chunk_host(drx_ctx *ctx, int reverse, size_t cd_nelmts,
+                                 const unsigned *cd_values, const void *in, size_t nbytes,
+                                 void **out, size_t *out_bytes);
+
+/* Kernel times of the plan's last call, measured with HIP events on the context's
+ * stream (needs the context option "profile" = 1 before the call; waits for it).
+ *   after drx_encode: ms = { size pass, offset scan, pack pass, whole call }
+ *   after drx_decode: ms = { header-chain walk, decode kernel, 0, whole call } */
+drx_status drx_plan_last_timings(drx_plan *plan, float ms[4]);
+
+/* Tuning / diagnostics: "decode_impl" selects a decode kernel variant, "profile"
+ * turns the event bracketing above on.  Returns DRX_ERR_ARG for unknown keys. */
+drx_status drx_ctx_set_option(drx_ctx *ctx, const char *key, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DELTARICE_HIP_H */

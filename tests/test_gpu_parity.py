@@ -1,0 +1,262 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle and the golden vectors.
+
+Everything here is bit-exact: integer codec, no tolerance."""
+import numpy as np
+import pytest
+
+from conftest import delta_only, golden_case_names
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import deltarice_amd as dr
+    c = dr.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def dev(ctx, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(ctx.device)
+
+
+def gpu_encode(ctx, plan, x):
+    enc = plan.encode(dev(ctx, x.reshape(-1).view(np.int16)))
+    return enc, *enc.to_numpy()
+
+
+IMPLS = [0, 1, 2, 3]
+
+
+# --------------------------------------------------------------------------- golden
+@pytest.mark.parametrize("name", golden_case_names())
+def test_golden_batch_api(ctx, O, golden, name):
+    g = golden[name]
+    if not delta_only(g["opts"]):
+        pytest.skip("general prediction filter: not on the device path (SURVEY 8f rank 2)")
+    x = O.decode_chunk(g["words"], g["opts"])
+    plan = ctx.plan_uniform(1, x.size, g["opts"])
+    enc, w, off = gpu_encode(ctx, plan, x)
+    assert off.tolist() == [0, g["n_words"]]
+    assert np.array_equal(w, g["words"]), "GPU encode differs from the reference's bytes"
+    for impl in IMPLS:
+        ctx.set_option("decode_impl", impl)
+        y = plan.decode(enc).cpu().numpy()
+        assert np.array_equal(y, x), f"GPU decode (impl {impl}) differs"
+    ctx.set_option("decode_impl", 1)
+
+
+@pytest.mark.parametrize("name", ["kat_docs", "config1_one_chunk", "leftover_20877", "uniform_default",
+                                  "arange_i16_delta", "cd1", "L5", "k15"])
+def test_golden_filter_callback_semantics(ctx, O, golden, name):
+    # the body of H5Z_filter_deltarice: host bytes in, host bytes out
+    g = golden[name]
+    x = O.decode_chunk(g["words"], g["opts"])
+    enc = ctx.filter_chunk(x, g["opts"], reverse=False)
+    assert enc == g["words"].tobytes()
+    dec = ctx.filter_chunk(g["words"], g["opts"], reverse=True)
+    assert dec == x.tobytes()
+
+
+# --------------------------------------------------------------------------- random vs oracle
+def make_data(rng, kind, n):
+    if kind == "gauss10":
+        return rng.normal(0, 10, n).astype(np.int16)
+    if kind == "gauss300":
+        return rng.normal(0, 300, n).astype(np.int16)
+    if kind == "uniform":
+        return rng.integers(-32768, 32768, n).astype(np.int16)
+    if kind == "zeros":
+        return np.zeros(n, np.int16)
+    if kind == "ramp":  # slope-1 ramp: codes of constant length (no self-synchronisation)
+        return (np.arange(n) % 60000 - 30000).astype(np.int16)
+    if kind == "steps":  # rare huge jumps -> isolated escapes
+        x = rng.normal(0, 3, n)
+        x[rng.integers(0, n, max(1, n // 500))] += rng.choice([-30000, 30000])
+        return x.clip(-32768, 32767).astype(np.int16)
+    raise ValueError(kind)
+
+
+CASES = [
+    # (n_chunks, chunk_samples, L, k, kind)
+    (3, 14000, 7000, 3, "gauss10"),
+    (5, 20 * 7000, 7000, 3, "gauss10"),
+    (2, 20877, 7000, 3, "gauss10"),       # leftover waveform
+    (4, 4096, 512, 3, "gauss300"),
+    (1, 65536, 0, 3, "uniform"),          # whole chunk = one waveform (default opts)
+    (2, 10000, 0, 4, "gauss10"),
+    (7, 1000, 1, 3, "gauss10"),           # one sample per waveform
+    (3, 999, 2, 2, "uniform"),
+    (3, 1000, 5, 3, "steps"),
+    (2, 6400, 63, 1, "gauss10"),
+    (2, 6400, 64, 5, "gauss300"),
+    (2, 6500, 65, 15, "uniform"),
+    (1, 3000, 30000, 3, "gauss10"),       # L > N
+    (9, 2048, 2048, 0, "gauss10"),        # M = 1
+    (2, 16384 * 2 + 100, 16384, 3, "gauss10"),
+    (65, 513, 513, 3, "gauss10"),         # > 64 waveforms, odd length (unaligned rows)
+    (1, 130 * 77, 77, 3, "steps"),        # > 2 decode waves, unaligned rows
+    (3, 7000 * 3, 7000, 3, "zeros"),
+    (2, 7000 * 4, 7000, 3, "ramp"),
+    (2, 7000 * 4, 7000, 1, "ramp"),
+    (1, 200000, 100000, 3, "gauss10"),    # long waveforms
+    (130, 70, 7, 3, "uniform"),
+]
+
+
+@pytest.mark.parametrize("n_chunks,chunk_samples,L,k,kind", CASES)
+def test_random_vs_oracle(ctx, O, n_chunks, chunk_samples, L, k, kind):
+    rng = np.random.default_rng(hash((n_chunks, chunk_samples, L, k)) & 0xFFFF)
+    x = make_data(rng, kind, n_chunks * chunk_samples)
+    opts = (1 << k,) if L == 0 else (1 << k, L)
+    ref_w, ref_off = O.encode_batch(x, chunk_samples, opts)
+    plan = ctx.plan_uniform(n_chunks, chunk_samples, opts)
+    enc, w, off = gpu_encode(ctx, plan, x)
+    assert np.array_equal(off, ref_off)
+    assert np.array_equal(w, ref_w)
+    # n_i table
+    nw = plan.wave_words()
+    assert int(nw.sum()) + nw.size + n_chunks == ref_w.size
+    for impl in IMPLS:
+        ctx.set_option("decode_impl", impl)
+        y = plan.decode(enc).cpu().numpy()
+        assert np.array_equal(y, x), f"impl {impl}"
+    ctx.set_option("decode_impl", 1)
+    # cross direction: oracle-encoded stream decoded on the GPU
+    enc2 = type(enc)(dev(ctx, ref_w.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), ref_w.size)
+    assert np.array_equal(plan.decode(enc2).cpu().numpy(), x)
+    # and GPU-encoded stream decoded by the oracle
+    assert np.array_equal(O.decode_batch(w, off, chunk_samples, opts), x)
+
+
+def test_ragged_mixed_waveform_lengths(ctx, O):
+    # BASELINE config #5: chunks with WaveformLength in {512, 2048, 7000, 16384}, m = 8, one call
+    rng = np.random.default_rng(5)
+    Ls = [512, 2048, 7000, 16384, 7000, 512, 16384, 2048, 0]
+    Ns = [512 * 40, 2048 * 9 + 17, 7000 * 3, 16384 * 2, 7000 * 2 + 1, 512 * 3, 16384 + 5, 2048, 4321]
+    xs = [rng.normal(0, 10, n).astype(np.int16) for n in Ns]
+    x = np.concatenate(xs)
+    plan = ctx.plan(Ns, Ls, 8)
+    enc, w, off = gpu_encode(ctx, plan, x)
+    at = 0
+    for c, (xc, L) in enumerate(zip(xs, Ls)):
+        ref = O.encode_chunk(xc, (8, L) if L else (8,))
+        assert off[c] == at
+        assert np.array_equal(w[at:at + ref.size], ref), f"chunk {c}"
+        at += ref.size
+    assert off[-1] == at == enc.total_words
+    for impl in IMPLS:
+        ctx.set_option("decode_impl", impl)
+        assert np.array_equal(plan.decode(enc).cpu().numpy(), x)
+    ctx.set_option("decode_impl", 1)
+
+
+def test_decode_chunks_in_arbitrary_order(ctx, O):
+    # chunk_word_off for decode is an input: chunks need not be in order or contiguous
+    rng = np.random.default_rng(12)
+    x = rng.normal(0, 10, (4, 3, 1000)).astype(np.int16)
+    opts = (8, 1000)
+    streams = [O.encode_chunk(x[c], opts) for c in range(4)]
+    order = [2, 0, 3, 1]
+    buf, starts, at = [], {}, 3
+    buf.append(np.zeros(3, np.uint32))
+    for c in order:
+        starts[c] = at
+        buf.append(streams[c]); buf.append(np.full(5, 0xDEADBEEF, np.uint32))
+        at += streams[c].size + 5
+    words = np.concatenate(buf)
+    plan = ctx.plan_uniform(4, 3000, opts)
+    import deltarice_amd as dr
+    # offsets table has n+1 entries where entry c+1 is the END of chunk c only for back-to-back
+    # chunks; for scattered chunks decode one plan per chunk
+    for c in range(4):
+        p1 = ctx.plan_uniform(1, 3000, opts)
+        off = np.array([starts[c], starts[c] + streams[c].size], np.int64)
+        enc = dr.EncodedBatch(dev(ctx, words.view(np.int32)), dev(ctx, off), words.size)
+        assert np.array_equal(p1.decode(enc).cpu().numpy(), x[c].ravel())
+
+
+def test_corrupt_stream_is_rejected_not_crashed(ctx, O):
+    import deltarice_amd as dr
+    x = np.random.default_rng(1).normal(0, 10, 7000 * 4).astype(np.int16)
+    opts = (8, 7000)
+    w = O.encode_chunk(x, opts)
+    plan = ctx.plan_uniform(1, x.size, opts)
+    for mutate in ("n_plus", "n_huge", "total", "truncated"):
+        bad = w.copy()
+        if mutate == "n_plus":
+            bad[1] += 1
+        elif mutate == "n_huge":
+            bad[1] = 0x7FFFFFFF
+        elif mutate == "total":
+            bad[0] += 1
+        else:
+            bad = bad[:-3]
+        enc = dr.EncodedBatch(dev(ctx, bad.view(np.int32)), dev(ctx, np.array([0, bad.size], np.int64)), bad.size)
+        for impl in IMPLS:
+            ctx.set_option("decode_impl", impl)
+            with pytest.raises(dr.DeltaRiceError) as e:
+                plan.decode(enc)
+            assert e.value.status == 4
+    ctx.set_option("decode_impl", 1)
+    with pytest.raises(dr.DeltaRiceError):
+        ctx.filter_chunk(w[:-1], opts, reverse=True)
+
+
+def test_capacity_error(ctx):
+    import deltarice_amd as dr
+    x = np.random.default_rng(2).integers(-32768, 32768, 7000 * 8).astype(np.int16)
+    plan = ctx.plan_uniform(2, 7000 * 4, (8, 7000))
+    with pytest.raises(dr.DeltaRiceError) as e:
+        plan.encode(dev(ctx, x), capacity_words=1000)
+    assert e.value.status == 3
+    enc = plan.encode(dev(ctx, x))  # plan still usable
+    assert np.array_equal(plan.decode(enc).cpu().numpy(), x)
+
+
+def test_bad_options_rejected(ctx):
+    import deltarice_amd as dr
+    for opts in [(0,), (3,), (65536,), (8, 0), (8, 1024, 0), (8, 0x80000000)]:
+        with pytest.raises(dr.DeltaRiceError):
+            ctx.plan_uniform(1, 1024, opts)
+    with pytest.raises(dr.DeltaRiceError):
+        ctx.filter_chunk(np.zeros(3, np.uint8), (8, 2))  # odd byte count (src/deltaRice.c:394-397)
+    with pytest.raises(dr.DeltaRiceError) as e:
+        ctx.filter_chunk(np.zeros(1024, np.int16), (8, 1024, 1, 1))
+    assert e.value.status == 5  # general prediction filters: loudly unsupported, never a CPU fallback
+
+
+# --------------------------------------------------------------------------- size-independent properties
+def test_large_batch_properties(ctx, O):
+    """BASELINE config #2 shape at 1/50 scale (20000 x 7000, 10 chunks of 2000 x 7000):
+    round trip, per-chunk framing invariants, and spot chunks against the oracle."""
+    n_chunks, W, L = 10, 2000, 7000
+    g = torch.Generator(device=ctx.device).manual_seed(1234)
+    x = (torch.randn(n_chunks * W * L, device=ctx.device, generator=g) * 10).to(torch.int16)
+    plan = ctx.plan_uniform(n_chunks, W * L, (8, L))
+    enc = plan.encode(x)
+    y = plan.decode(enc)
+    assert torch.equal(x, y)
+    ratio = enc.total_words * 4 / (x.numel() * 2)
+    assert 0.40 < ratio < 0.41  # 0.4043 for this distribution
+    off = enc.chunk_word_off.cpu().numpy()
+    nw = plan.wave_words().reshape(n_chunks, W)
+    assert np.array_equal(np.diff(off), 1 + W + nw.sum(axis=1))  # checksum of the framing
+    hdr = enc.words[torch.from_numpy(off[:-1]).to(ctx.device)].cpu().numpy()
+    assert np.all(hdr == W * L)
+    for c in (0, 7):
+        xc = x[c * W * L:(c + 1) * W * L].cpu().numpy()
+        assert enc.chunk_bytes(c) == O.encode_chunk(xc, (8, L)).tobytes()
+    # idempotence: encoding the decoded batch gives the same stream
+    enc2 = plan.encode(y)
+    assert enc2.total_words == enc.total_words
+    assert torch.equal(enc2.words[:enc2.total_words], enc.words[:enc.total_words])

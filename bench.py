@@ -45,7 +45,7 @@ def parse_args():
     ap.add_argument("--chunk-waves", type=int, default=2000, help="waveforms per HDF5 chunk")
     ap.add_argument("--m", type=int, default=8, help="RiceParameter")
     ap.add_argument("--dist", choices=["gauss", "ar1"], default="gauss")
-    ap.add_argument("--decode-impl", type=int, default=1)
+    ap.add_argument("--decode-impl", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0: skip)")
     ap.add_argument("--seed", type=int, default=1234)
     return ap.parse_args()
@@ -153,7 +153,8 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    total_words = plan.finish()
+    plan.finish()
+    total_words = int(off[-1].item())
     assert torch.equal(x, y), "round trip failed"  # gating, not timed
     ratio = total_words * 4 / raw_bytes
 

@@ -45,9 +45,10 @@ def parse_args():
     ap.add_argument("--chunk-waves", type=int, default=2000, help="waveforms per HDF5 chunk")
     ap.add_argument("--m", type=int, default=8, help="RiceParameter")
     ap.add_argument("--dist", choices=["gauss", "ar1"], default="gauss")
-    ap.add_argument("--decode-impl", type=int, default=2)
+    ap.add_argument("--decode-impl", type=int, default=21)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0: skip)")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--debug-flags", type=int, default=0, help="kernel ablation switches (profiling only; results invalid)")
     return ap.parse_args()
 
 
@@ -127,6 +128,8 @@ def main():
     ctx = dr.Context(local)
     ctx.set_option("decode_impl", a.decode_impl)
     ctx.set_option("profile", 1)
+    if a.debug_flags:
+        ctx.set_option("debug_flags", a.debug_flags)
     dev = ctx.device
     L, W = a.wave_len, a.chunk_waves
     n_waves = (a.waves // W) * W
@@ -155,7 +158,7 @@ def main():
         step()
     plan.finish()
     total_words = int(off[-1].item())
-    assert torch.equal(x, y), "round trip failed"  # gating, not timed
+    assert a.debug_flags or torch.equal(x, y), "round trip failed"  # gating, not timed
     ratio = total_words * 4 / raw_bytes
 
     def barrier():

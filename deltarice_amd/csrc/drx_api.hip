@@ -23,8 +23,9 @@ struct drx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    int decode_impl = 1;  // 0 simple, 1 staged <64,64>, 2 <64,32>, 3 <128,64>
+    int decode_impl = 21;  // see launch_decode(); 0 = simple reference kernel
     int profile = 0;      // bracket kernels with HIP events (drx_plan_last_timings)
+    uint32_t debug_flags = 0;  // Geom::dbg
     std::string last_error;
     // scratch of the one-chunk host path (drx_filter_chunk_host), grown on demand
     void *d_raw = nullptr;   size_t raw_cap = 0;
@@ -161,8 +162,12 @@ void *drx_ctx_stream(const drx_ctx *c) { return c ? (void *)c->stream : nullptr;
 drx_status drx_ctx_set_option(drx_ctx *c, const char *key, int64_t value) {
     if (!c || !key) return DRX_ERR_ARG;
     if (!strcmp(key, "decode_impl")) {
-        if (value < 0 || value > 3) return DRX_ERR_ARG;
+        if (value < 0 || value > 23) return DRX_ERR_ARG;
         c->decode_impl = (int)value;
+        return DRX_OK;
+    }
+    if (!strcmp(key, "debug_flags")) {
+        c->debug_flags = (uint32_t)value;
         return DRX_OK;
     }
     if (!strcmp(key, "profile")) {
@@ -314,6 +319,7 @@ drx_status drx_decode(drx_plan *p, const uint32_t *d_in, uint64_t in_words,
     drx_ctx *ctx = p->ctx;
     DRX_HIP(ctx, hipSetDevice(ctx->device));
     DRX_HIP(ctx, hipMemsetAsync(p->d_status, 0, sizeof(DevStatus), ctx->stream));
+    p->G.dbg = ctx->debug_flags;
     DRX_HIP(ctx, launch_decode(p->G, d_in, in_words, d_chunk_word_off, d_out, p->d_wave_off,
                                p->d_wave_words, p->d_status, ctx->decode_impl, ctx->profile ? p->ev : nullptr,
                                ctx->stream));

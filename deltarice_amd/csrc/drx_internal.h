@@ -25,6 +25,8 @@ struct Geom {
     uint32_t uniform;  // all chunks share (n_samples, wave_len): pure arithmetic mapping
     uint32_t u_n_samples, u_wave_len, u_n_waves;
     uint32_t k;  // log2(M)
+    uint32_t dbg;  // ablation switches for profiling builds of the decode kernel (0 in normal use):
+                   // bit 0: skip the output stores, bit 1: skip the stream loads
 };
 
 struct DevStatus {

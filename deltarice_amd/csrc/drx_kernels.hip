@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "drx_internal.h"
 
 namespace drx {
@@ -527,6 +529,796 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
     }
 }
 
+// Second-generation staged decoder.  Same decomposition as k_decode_lanes (one lane per
+// waveform, LDS ring per lane, LDS transpose of the output), restructured around latency
+// and occupancy (rocprofv3 PMC, profiles/r01_*: the first version spent 34 % of its wave
+// cycles in s_waitcnt and 55 % of its LDS cycles in bank conflicts, at 7 waves per CU):
+//   * the per-sample loop is branch free: the next stream word is prefetched from the ring
+//     one refill ahead, so neither LDS latency nor an exec-mask branch sits on the serial
+//     bit-position recurrence;
+//   * the ring is word-major, ring[slot][lane]: a lane's bank is its lane number whatever
+//     slot it reads, so the per-sample reads never conflict although the 64 streams drift;
+//   * every lane fetches its own next piece (LW words: a whole 128-byte line, or half of
+//     one) with 16-byte loads issued back to back and one wait; each byte of the stream is
+//     requested exactly once;
+//   * RW = 32 ring words (two 64-byte pieces) and T = 16..32 keep a wave at ~11-13 KB of
+//     LDS, i.e. 12-14 waves per CU instead of 7.
+template <int RW, int LW, int T>
+__global__ __launch_bounds__(64) void k_decode_lanes2(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
+                                                      const uint64_t *__restrict__ wave_off,
+                                                      const uint32_t *__restrict__ wave_words,
+                                                      int16_t *__restrict__ out) {
+    static_assert(RW >= 2 * LW && (RW & (RW - 1)) == 0 && (LW == 16 || LW == 32), "ring geometry");
+    constexpr int OSW = T / 2 + 1;  // output row stride in words (odd: conflict-free rows)
+    constexpr int PPS = T / 8;      // 16-byte pieces per stream per round
+    constexpr int SPI = 64 / PPS;   // streams per write-out iteration
+    constexpr int NV = LW / 4;      // 16-byte loads per piece
+    __shared__ uint32_t ring[RW * 64];
+    __shared__ uint32_t obuf[64 * OSW];
+    __shared__ uint64_t tab_ooff[64];
+    __shared__ uint32_t tab_len[64];
+
+    const int lane = lane_id();
+    const uint64_t g = (uint64_t)blockIdx.x * 64u + lane;
+    const bool active = g < G.total_waves;
+    const uint32_t k = G.k;
+
+    uint32_t len = 0, n = 0;
+    uint64_t S = 0, ooff = 0;
+    if (active) {
+        const WaveRef r = locate(G, g);
+        len = r.len;
+        ooff = r.sample_off;
+        S = wave_off[g] + 1u;
+        n = wave_words[g];
+    }
+    tab_ooff[lane] = ooff;
+    tab_len[lane] = len;
+    const uint64_t A = S & ~(uint64_t)(RW - 1);  // ring slot of word w = (w - A) mod RW
+    const uint32_t s0 = (uint32_t)(S - A);
+    const uint32_t endw = s0 + n;
+    uint32_t flw = s0 & ~(uint32_t)(LW - 1);  // words loaded so far (whole pieces), relative to A
+    uint32_t rdw = s0;  // index of the word held in `nxt` (after start-up); words >= rdw stay in the ring
+    const bool in_vec_ok = ((uintptr_t)in & 15u) == 0;
+    const uint32_t maxlen = wave_max_u32(len);
+    uint32_t *myring = ring + lane;  // slot i of this lane: myring[i * 64]
+    typedef uint16_t __attribute__((may_alias)) u16a;
+    u16a *myout = reinterpret_cast<u16a *>(obuf + lane * OSW);
+
+    auto top_up = [&]() {
+        for (;;) {
+            // a new piece overwrites the slots of words [flw-RW, flw-RW+LW): all must be < rdw
+            const bool need = (flw < endw) && (flw + (uint32_t)LW <= rdw + (uint32_t)RW);
+            if (__ballot(need) == 0) break;
+            if (need && !(G.dbg & 2u)) {
+                const uint64_t a = A + flw;
+                uint4 v[NV];
+                if (in_vec_ok && a + (uint32_t)LW <= in_words) {
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const uint4 *>(in + a + 4 * j);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) {
+                        v[j].x = (a + 4 * j + 0 < in_words) ? in[a + 4 * j + 0] : 0u;
+                        v[j].y = (a + 4 * j + 1 < in_words) ? in[a + 4 * j + 1] : 0u;
+                        v[j].z = (a + 4 * j + 2 < in_words) ? in[a + 4 * j + 2] : 0u;
+                        v[j].w = (a + 4 * j + 3 < in_words) ? in[a + 4 * j + 3] : 0u;
+                    }
+                }
+                uint32_t *dst = myring + (flw & (uint32_t)(RW - 1)) * 64u;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    dst[(4 * j + 0) * 64] = v[j].x; dst[(4 * j + 1) * 64] = v[j].y;
+                    dst[(4 * j + 2) * 64] = v[j].z; dst[(4 * j + 3) * 64] = v[j].w;
+                }
+            }
+            if (need) flw += (uint32_t)LW;
+            wave_sync();
+        }
+    };
+
+    wave_sync();
+    top_up();
+    // window = alignbit(hi, lo, s): the 32 stream bits that start s bits above the bottom of hi
+    uint32_t hi = 0, lo = myring[(rdw & (RW - 1)) * 64u];
+    ++rdw;
+    uint32_t nxt = myring[(rdw & (RW - 1)) * 64u];
+    int32_t s = 0;
+    int32_t acc = 0;
+    const uint32_t kp1 = k + 1u, c31k = 31u - k;
+
+    for (uint32_t t0 = 0; t0 < maxlen; t0 += T) {
+#pragma unroll 1
+        for (int tg = 0; tg < T; tg += 4) {
+            // a group of 4 samples moves the prefetch pointer by at most 4 words
+            if (__any((flw - rdw < 6u) && (flw < endw))) top_up();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t win = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)s);
+                uint32_t q;  // leading zeros; 0xffffffff for win == 0, which is an escape anyway
+                asm("v_ffbh_u32 %0, %1" : "=v"(q) : "v"(win));
+                const bool esc = win < (1u << 24);  // 8 (or more) leading zeros
+                const uint32_t rem = __builtin_amdgcn_ubfe(win, c31k - q, k);
+                const uint32_t z_ne = (q << k) + rem;
+                const uint32_t z = esc ? __builtin_amdgcn_ubfe(win, 7u, 16u) : z_ne;
+                const uint32_t used = esc ? 25u : q + kp1;
+                acc += (int32_t)(z >> 1) ^ -(int32_t)(z & 1u);
+                myout[tg + u] = (uint16_t)acc;
+                const int32_t s2 = s - (int32_t)used;
+                const bool take = s2 < 0;
+                s = s2 & 31;
+                hi = take ? lo : hi;
+                lo = take ? nxt : lo;
+                rdw += take ? 1u : 0u;
+                nxt = myring[(rdw & (RW - 1)) * 64u];
+            }
+        }
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < PPS; ++i) {
+            const int st = i * SPI + lane / PPS, p = lane % PPS;
+            const uint32_t slen = tab_len[st];
+            const uint32_t tpos = t0 + 8u * (uint32_t)p;
+            if (tpos < slen && !(G.dbg & 1u)) {
+                const uint32_t *src = obuf + st * OSW + 4 * p;
+                uint4 v;
+                v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
+                int16_t *dst = out + tab_ooff[st] + tpos;
+                if (tpos + 8u <= slen && ((uintptr_t)dst & 15u) == 0) {
+                    *reinterpret_cast<uint4 *>(dst) = v;
+                } else {
+                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (tpos + (uint32_t)j < slen) dst[j] = (int16_t)(w[j >> 1] >> (16 * (j & 1)));
+                }
+            }
+        }
+        wave_sync();
+    }
+}
+
+// Third-generation staged decoder: minimum VALU work per sample.
+//
+// Measured (profiles/r01_*): with loads and stores ablated k_decode_lanes2 takes the same
+// 1.4 ms per 1.4e9 samples at 7 and at 12 waves per CU -- the kernel is bound by VALU issue
+// (a wave64 VALU instruction occupies its SIMD for 4 cycles), not by latency or HBM.  So the
+// lever is instructions per sample.  Here the bit position is kept negated, Q = -P (mod 2^32),
+// and the ring is stored in reverse word order with one mirror row, so that
+//     row   = Q[5 +: log2 RW]            (v_bfe)        row of the word after the current one
+//     words = ring[row], ring[row + 1]   (ds_read2_b32) "lo" and "hi"
+//     win   = alignbit(hi, lo, Q)        (shift uses Q[4:0])
+// forms the 32-bit window in 3 VALU + 1 LDS instruction with no per-sample refill state at
+// all; escape and ordinary codes share one extraction (payload width kk = esc ? 16 : k; the
+// stray high bits an escape leaves above bit 15 never reach the int16 running sum).
+template <int RW, int LW, int T, bool ALIGNED>
+__global__ __launch_bounds__(64) void k_decode_lanes3(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
+                                                      const uint64_t *__restrict__ wave_off,
+                                                      const uint32_t *__restrict__ wave_words,
+                                                      int16_t *__restrict__ out) {
+    static_assert(RW >= 2 * LW && (RW == 32 || RW == 64 || RW == 128) && (LW == 16 || LW == 32), "ring geometry");
+    constexpr int LOG_RW = RW == 32 ? 5 : (RW == 64 ? 6 : 7);
+    constexpr int GS = 8;           // samples between two refill checks
+    constexpr int OSW = T / 2 + 1;  // output row stride in words (odd: conflict-free rows)
+    constexpr int PPS = T / 8;      // 16-byte pieces per stream per round
+    constexpr int SPI = 64 / PPS;   // streams per write-out iteration
+    constexpr int NV = LW / 4;      // 16-byte loads per piece
+    constexpr uint32_t WMASK = (1u << 27) - 1u;  // word indices derived from Q live mod 2^27
+    static_assert(T % GS == 0, "round length");
+    // ring row r (r = 0..RW) holds, for every lane, the stream word w with RW - (w mod RW) == r;
+    // row 0 mirrors row RW so that the pair (w, w+1) is always (row+1, row).
+    __shared__ uint32_t ring[(RW + 1) * 64];
+    __shared__ uint32_t obuf[64 * OSW];
+    __shared__ uint64_t tab_ooff[64];  // sample offset of step 0 of round 0 (may lie before the waveform)
+    __shared__ uint32_t tab_lo[64];    // first and one-past-last step of the stream that carry samples
+    __shared__ uint32_t tab_hi[64];
+
+    const int lane = lane_id();
+    const uint64_t g = (uint64_t)blockIdx.x * 64u + lane;
+    const bool active = g < G.total_waves;
+    const uint32_t k = G.k;
+
+    uint32_t len = 0, n = 0;
+    uint64_t S = 1, ooff = 0;
+    if (active) {
+        const WaveRef r = locate(G, g);
+        len = r.len;
+        ooff = r.sample_off;
+        S = wave_off[g] + 1u;
+        n = wave_words[g];
+    }
+    // ALIGNED: lane-private start delay phi so that step u of every round lands on a sample whose
+    // address is u*2 past a T*2-byte boundary: each round then stores whole aligned sectors
+    // (rocprofv3: unaligned 64-byte pieces made the L2 emit 1.6x the write requests).
+    const uint32_t phi = (ALIGNED && active) ? (uint32_t)((((uintptr_t)out >> 1) + ooff) & (uint64_t)(T - 1)) : 0u;
+    tab_ooff[lane] = ooff - phi;
+    tab_lo[lane] = phi;
+    tab_hi[lane] = phi + len;
+    // word indices are relative to A, one whole ring below the stream start, so s0 is in [RW, 2 RW)
+    const uint64_t A = (S & ~(uint64_t)(RW - 1)) - (uint64_t)RW;
+    const uint32_t s0 = (uint32_t)(S - A);
+    const uint32_t endw = s0 + n;
+    uint32_t flw = s0 & ~(uint32_t)(LW - 1);  // words loaded so far (whole pieces)
+    const bool in_vec_ok = ((uintptr_t)in & 15u) == 0;
+    const uint32_t maxlen = wave_max_u32(len + phi);
+    uint32_t *myring = ring + lane;
+    typedef uint16_t __attribute__((may_alias)) u16a;
+    u16a *myout = reinterpret_cast<u16a *>(obuf + lane * OSW);
+
+    // loads the piece [flw, flw + LW) of this lane's stream into its ring rows
+    auto load_piece = [&](bool need) {
+        if (need && !(G.dbg & 2u)) {
+            const uint64_t a = A + flw;
+            uint4 v[NV];
+            if (in_vec_ok && a + (uint32_t)LW <= in_words) {
+#pragma unroll
+                for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const uint4 *>(in + a + 4 * j);
+            } else {
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    v[j].x = (a + 4 * j + 0 < in_words) ? in[a + 4 * j + 0] : 0u;
+                    v[j].y = (a + 4 * j + 1 < in_words) ? in[a + 4 * j + 1] : 0u;
+                    v[j].z = (a + 4 * j + 2 < in_words) ? in[a + 4 * j + 2] : 0u;
+                    v[j].w = (a + 4 * j + 3 < in_words) ? in[a + 4 * j + 3] : 0u;
+                }
+            }
+            const uint32_t r0 = (uint32_t)RW - (flw & (uint32_t)(RW - 1));  // row of the piece's first word
+            uint32_t *dst = myring + r0 * 64u;                              // following words: rows r0-1, r0-2, ...
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                dst[-(4 * j + 0) * 64] = v[j].x; dst[-(4 * j + 1) * 64] = v[j].y;
+                dst[-(4 * j + 2) * 64] = v[j].z; dst[-(4 * j + 3) * 64] = v[j].w;
+            }
+            if (r0 == (uint32_t)RW) myring[0] = v[0].x;  // mirror row
+        }
+        if (need) flw += (uint32_t)LW;
+    };
+
+    uint32_t Q = 0u - 32u * s0;  // minus the bit position (relative to A)
+
+    auto top_up = [&]() {
+        for (;;) {
+            const uint32_t cw = (~Q) >> 5;  // word that holds the bit before the current one; words >= cw are live
+            const uint32_t avail = (flw - cw) & WMASK;
+            // the new piece overwrites the rows of words [flw-RW, flw-RW+LW): all must be < cw
+            const bool need = (flw < endw) && (avail <= (uint32_t)(RW - LW));
+            if (__ballot(need) == 0) break;
+            load_piece(need);
+            wave_sync();
+        }
+    };
+
+    wave_sync();
+    load_piece(flw < endw);  // start-up: the piece that holds word s0 and the one after it
+    load_piece(flw < endw);
+    wave_sync();
+    int32_t acc = 0;
+
+    auto run_round = [&](auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;  // round 0: steps < phi are idle for this lane
+#pragma unroll 1
+        for (int tg = 0; tg < T; tg += GS) {
+            {   // GS samples touch words up to cw + GS + 1
+                const uint32_t cw = (~Q) >> 5;
+                if (__any((((flw - cw) & WMASK) < (uint32_t)(GS + 2)) && (flw < endw))) top_up();
+            }
+#pragma unroll
+            for (int u = 0; u < GS; ++u) {
+                const uint32_t row = __builtin_amdgcn_ubfe(Q, 5u, (uint32_t)LOG_RW);
+                const uint32_t *wp = myring + row * 64u;
+                const uint32_t lo = wp[0], hi = wp[64];
+                const uint32_t win = __builtin_amdgcn_alignbit(hi, lo, Q);
+                // leading zeros; win == 0 only occurs past the end of a (corrupt) stream, where any value will do
+                const uint32_t q = (uint32_t)__builtin_clz(win);
+                const bool esc = win < (1u << 24);
+                const uint32_t kk = esc ? 16u : k;
+                const uint32_t used = q + kk + 1u;
+                const uint32_t rem = __builtin_amdgcn_ubfe(win, 32u - used, kk);
+                const uint32_t z = (q << kk) + rem;  // escape: 8 << 16 stays above bit 15
+                const int32_t d = (int32_t)(z >> 1) ^ -(int32_t)(z & 1u);
+                if (FIRST && ALIGNED) {
+                    const bool act = (uint32_t)(tg + u) >= phi;
+                    acc = act ? acc + d : acc;
+                    Q = act ? Q - used : Q;
+                } else {
+                    acc += d;
+                    Q -= used;
+                }
+                myout[tg + u] = (uint16_t)acc;
+            }
+        }
+    };
+
+    for (uint32_t t0 = 0; t0 < maxlen; t0 += T) {
+        if (ALIGNED && t0 == 0) run_round(std::true_type{});
+        else run_round(std::false_type{});
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < PPS; ++i) {
+            const int st = i * SPI + lane / PPS, p = lane % PPS;
+            const uint32_t slo = tab_lo[st], shi = tab_hi[st];
+            const uint32_t tpos = t0 + 8u * (uint32_t)p;  // step index of the piece's first sample
+            if (tpos + 8u > slo && tpos < shi && !(G.dbg & 1u)) {
+                const uint32_t *src = obuf + st * OSW + 4 * p;
+                uint4 v;
+                v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
+                int16_t *dst = out + tab_ooff[st] + tpos;
+                if (tpos >= slo && tpos + 8u <= shi && ((uintptr_t)dst & 15u) == 0) {
+                    *reinterpret_cast<uint4 *>(dst) = v;
+                } else {
+                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (tpos + (uint32_t)j >= slo && tpos + (uint32_t)j < shi)
+                            dst[j] = (int16_t)(w[j >> 1] >> (16 * (j & 1)));
+                }
+            }
+        }
+        wave_sync();
+    }
+}
+
+// Fourth generation: k_decode_lanes3's per-sample core with the per-round overheads
+// trimmed (PMC: the core is 14.5 VALU per sample and VALU issue, 4 cycles per wave64
+// instruction, is the binding resource, so everything around the core is pure loss):
+//   * stream pieces are prefetched: the loads of a piece are issued as soon as most lanes
+//     have room for it and are written to the ring only when a lane is about to need
+//     them, so the ~2 us HBM round trip overlaps ~100 samples of decoding instead of
+//     stalling the wave 60-odd times per waveform;
+//   * the write-out of interior rounds (every stream fully inside its waveform -- all but
+//     the first and last round or two) is one ds_read_b128 + one 16-byte store per piece,
+//     with the piece addresses held in registers;
+//   * refill checks every 16 samples instead of every 8.
+template <int RW, int LW, int T>
+__global__ __launch_bounds__(64) void k_decode_lanes4(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
+                                                      const uint64_t *__restrict__ wave_off,
+                                                      const uint32_t *__restrict__ wave_words,
+                                                      int16_t *__restrict__ out) {
+    static_assert(RW >= 2 * LW && (RW == 32 || RW == 64 || RW == 128) && (LW == 16 || LW == 32), "ring geometry");
+    constexpr int LOG_RW = RW == 32 ? 5 : (RW == 64 ? 6 : 7);
+    constexpr int GS = 16;          // samples between two refill checks
+    constexpr int OSW = T / 2 + 4;  // output row stride in words (16-byte aligned rows)
+    constexpr int PPS = T / 8;      // 16-byte pieces per stream per round
+    constexpr int SPI = 64 / PPS;   // streams per write-out iteration
+    constexpr int NV = LW / 4;      // 16-byte loads per piece
+    constexpr uint32_t WMASK = (1u << 27) - 1u;
+    constexpr uint32_t ISSUE_AT = RW - LW - 8;  // prefetch once some lane is this far into its free space
+    static_assert(T % GS == 0 && RW - LW >= GS + 2, "round length / ring slack");
+    __shared__ uint32_t ring[(RW + 1) * 64];  // row r: word w with RW - (w mod RW) == r; row 0 mirrors row RW
+    __shared__ __attribute__((aligned(16))) uint32_t obuf[64 * OSW];
+    __shared__ uint64_t tab_base[64];  // byte address of step 0 of round 0 of each stream
+    __shared__ uint32_t tab_lo[64], tab_hi[64];
+
+    const int lane = lane_id();
+    const uint64_t g = (uint64_t)blockIdx.x * 64u + lane;
+    const bool active = g < G.total_waves;
+    const uint32_t k = G.k;
+
+    uint32_t len = 0, n = 0;
+    uint64_t S = 1, ooff = 0;
+    if (active) {
+        const WaveRef r = locate(G, g);
+        len = r.len;
+        ooff = r.sample_off;
+        S = wave_off[g] + 1u;
+        n = wave_words[g];
+    }
+    // start delay: step u of every round sits u*2 bytes past a T*2-byte boundary (see k_decode_lanes3)
+    const uint32_t phi = active ? (uint32_t)((((uintptr_t)out >> 1) + ooff) & (uint64_t)(T - 1)) : 0u;
+    tab_base[lane] = (uint64_t)(uintptr_t)out + 2u * (ooff - phi);
+    tab_lo[lane] = phi;
+    tab_hi[lane] = phi + len;
+    const uint32_t steps = wave_max_u32(len + phi);
+    const uint32_t lo_max = wave_max_u32(phi);
+    const uint32_t hi_min = ~wave_max_u32(~(phi + len));
+
+    const uint64_t A = (S & ~(uint64_t)(RW - 1)) - (uint64_t)RW;  // s0 in [RW, 2 RW)
+    const uint32_t s0 = (uint32_t)(S - A);
+    const uint32_t endw = s0 + n;
+    uint32_t flw = s0 & ~(uint32_t)(LW - 1);
+    const bool in_vec_ok = ((uintptr_t)in & 15u) == 0;
+    uint32_t *myring = ring + lane;
+    typedef uint16_t __attribute__((may_alias)) u16a;
+    u16a *myout = reinterpret_cast<u16a *>(obuf + lane * OSW);
+    wave_sync();
+
+    // write-out constants of this lane: piece p of stream st_i, i = 0..PPS-1
+    uint64_t wo_addr[PPS];
+    uint32_t wo_lo[PPS], wo_hi[PPS];
+#pragma unroll
+    for (int i = 0; i < PPS; ++i) {
+        const int st = i * SPI + lane / PPS, p = lane % PPS;
+        wo_addr[i] = tab_base[st] + 16u * (uint32_t)p;
+        wo_lo[i] = tab_lo[st];
+        wo_hi[i] = tab_hi[st];
+    }
+
+    uint4 pv[NV];        // piece in flight
+    bool pneed = false;  // this lane has a piece in flight
+    bool pend = false;   // some lane has (wave uniform)
+
+    auto issue = [&](bool need) {
+        pneed = need;
+        if (need && !(G.dbg & 2u)) {
+            const uint64_t a = A + flw;
+            if (in_vec_ok && a + (uint32_t)LW <= in_words) {
+#pragma unroll
+                for (int j = 0; j < NV; ++j) pv[j] = *reinterpret_cast<const uint4 *>(in + a + 4 * j);
+            } else {
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    pv[j].x = (a + 4 * j + 0 < in_words) ? in[a + 4 * j + 0] : 0u;
+                    pv[j].y = (a + 4 * j + 1 < in_words) ? in[a + 4 * j + 1] : 0u;
+                    pv[j].z = (a + 4 * j + 2 < in_words) ? in[a + 4 * j + 2] : 0u;
+                    pv[j].w = (a + 4 * j + 3 < in_words) ? in[a + 4 * j + 3] : 0u;
+                }
+            }
+        }
+    };
+    auto commit = [&]() {
+        if (pneed) {
+            if (!(G.dbg & 2u)) {
+                const uint32_t r0 = (uint32_t)RW - (flw & (uint32_t)(RW - 1));
+                uint32_t *dst = myring + r0 * 64u;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    dst[-(4 * j + 0) * 64] = pv[j].x; dst[-(4 * j + 1) * 64] = pv[j].y;
+                    dst[-(4 * j + 2) * 64] = pv[j].z; dst[-(4 * j + 3) * 64] = pv[j].w;
+                }
+                if (r0 == (uint32_t)RW) myring[0] = pv[0].x;
+            }
+            flw += (uint32_t)LW;
+        }
+        pneed = false;
+        wave_sync();
+    };
+
+    uint32_t Q = 0u - 32u * s0;  // minus the bit position (relative to A)
+    issue(flw < endw); commit();  // start-up: the piece holding word s0 and the one after it
+    issue(flw < endw); commit();
+    int32_t acc = 0;
+
+    // refill policy, run every GS samples (GS samples touch words up to cw + GS + 1)
+    auto refill = [&]() {
+        uint32_t avail = (flw - ((~Q) >> 5)) & WMASK;
+        if (pend && __any((flw < endw) && avail < (uint32_t)(GS + 2))) { commit(); pend = false; }
+        if (!pend) {
+            for (;;) {  // lanes that were not part of the last piece may be dry: serve them synchronously
+                avail = (flw - ((~Q) >> 5)) & WMASK;
+                if (!__any((flw < endw) && avail < (uint32_t)(GS + 2))) break;
+                issue((flw < endw) && avail <= (uint32_t)(RW - LW));
+                commit();
+            }
+            if (__any((flw < endw) && avail <= ISSUE_AT)) {
+                issue((flw < endw) && avail <= (uint32_t)(RW - LW));
+                pend = true;
+            }
+        }
+    };
+
+    auto run_round = [&](auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;  // round 0: steps < phi are idle for this lane
+#pragma unroll 1
+        for (int tg = 0; tg < T; tg += GS) {
+            refill();
+#pragma unroll
+            for (int u = 0; u < GS; ++u) {
+                const uint32_t row = __builtin_amdgcn_ubfe(Q, 5u, (uint32_t)LOG_RW);
+                const uint32_t *wp = myring + row * 64u;
+                const uint32_t lo = wp[0], hi = wp[64];
+                const uint32_t win = __builtin_amdgcn_alignbit(hi, lo, Q);
+                const uint32_t q = (uint32_t)__builtin_clz(win);  // win == 0 only past the end of a corrupt stream
+                const bool esc = win < (1u << 24);
+                const uint32_t kk = esc ? 16u : k;
+                const uint32_t used = q + kk + 1u;
+                const uint32_t rem = __builtin_amdgcn_ubfe(win, 32u - used, kk);
+                const uint32_t z = (q << kk) + rem;  // escape: 8 << 16 stays above bit 15
+                const int32_t d = (int32_t)(z >> 1) ^ -(int32_t)(z & 1u);
+                if (FIRST) {
+                    const bool act = (uint32_t)(tg + u) >= phi;
+                    acc = act ? acc + d : acc;
+                    Q = act ? Q - used : Q;
+                } else {
+                    acc += d;
+                    Q -= used;
+                }
+                myout[tg + u] = (uint16_t)acc;
+            }
+        }
+    };
+
+    for (uint32_t t0 = 0; t0 < steps; t0 += T) {
+        if (t0 == 0) run_round(std::true_type{});
+        else run_round(std::false_type{});
+        wave_sync();
+        if (!(G.dbg & 1u)) {
+            if (t0 >= lo_max && t0 + T <= hi_min) {  // interior round: whole aligned pieces only
+#pragma unroll
+                for (int i = 0; i < PPS; ++i) {
+                    const int st = i * SPI + lane / PPS, p = lane % PPS;
+                    const uint4 v = *reinterpret_cast<const uint4 *>(obuf + st * OSW + 4 * p);
+                    uint4 *dst4 = reinterpret_cast<uint4 *>(wo_addr[i] + 2u * (uint64_t)t0);
+                    if (G.dbg & 4u) {
+                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                        u32x4 nv = {v.x, v.y, v.z, v.w};
+                        __builtin_nontemporal_store(nv, reinterpret_cast<u32x4 *>(dst4));
+                    } else {
+                        *dst4 = v;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < PPS; ++i) {
+                    const int st = i * SPI + lane / PPS, p = lane % PPS;
+                    const uint32_t tpos = t0 + 8u * (uint32_t)p;  // step index of the piece's first sample
+                    if (tpos + 8u > wo_lo[i] && tpos < wo_hi[i]) {
+                        const uint4 v = *reinterpret_cast<const uint4 *>(obuf + st * OSW + 4 * p);
+                        int16_t *dst = reinterpret_cast<int16_t *>(wo_addr[i] + 2u * (uint64_t)t0);
+                        if (tpos >= wo_lo[i] && tpos + 8u <= wo_hi[i]) {
+                            *reinterpret_cast<uint4 *>(dst) = v;
+                        } else {
+                            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                if (tpos + (uint32_t)j >= wo_lo[i] && tpos + (uint32_t)j < wo_hi[i])
+                                    dst[j] = (int16_t)(w[j >> 1] >> (16 * (j & 1)));
+                        }
+                    }
+                }
+            }
+        }
+        wave_sync();
+    }
+}
+
+// Fifth generation = k_decode_lanes4 reshaped by what the store micro-benchmark showed
+// (tools/ubench_store.hip, profiles/r01_ubench_store.txt): 16-byte stores reach 5.5 TB/s
+// only when every contiguous run is a whole 128-byte line; 64-byte aligned runs give
+// 4.2 TB/s and runs that straddle lines 2.6-3.3 TB/s whatever their length.  So T = 64:
+// every round ends with one aligned 128-byte line per waveform.  Also fixed here: stores
+// are global_ (not flat_) instructions, the prefetched piece never crosses a duplicated
+// loop body (the start-up round refills synchronously), the in-flight piece is committed
+// before the round's stores are issued (vmcnt is in order: a load issued after a store
+// cannot be waited for without waiting for the store), and the refill test is one
+// compare against a per-lane limit position.
+template <int RW, int LW, int T, int GS>
+__global__ __launch_bounds__(64) void k_decode_lanes5(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
+                                                      const uint64_t *__restrict__ wave_off,
+                                                      const uint32_t *__restrict__ wave_words,
+                                                      int16_t *__restrict__ out) {
+    static_assert(RW >= 2 * LW && (RW == 32 || RW == 64 || RW == 128) && (LW == 8 || LW == 16 || LW == 32), "ring");
+    constexpr int LOG_RW = RW == 32 ? 5 : (RW == 64 ? 6 : 7);
+    constexpr int OSW = T / 2 + 4;  // output row stride in words (16-byte aligned rows)
+    constexpr int PPS = T / 8;      // 16-byte pieces per stream per round
+    constexpr int SPI = 64 / PPS;   // streams per write-out iteration
+    constexpr int NV = LW / 4;      // 16-byte loads per piece
+    constexpr uint32_t WMASK = (1u << 27) - 1u;
+    constexpr uint32_t NEED_AT = GS + 2;                                   // must refill below this many words
+    constexpr uint32_t ISSUE_AT = (RW - LW) > NEED_AT + 4 ? RW - LW - 2 : RW - LW;  // start prefetching here
+    static_assert(T % GS == 0 && RW - LW >= GS + 2, "round length / ring slack");
+    __shared__ uint32_t ring[(RW + 1) * 64];  // row r: word w with RW - (w mod RW) == r; row 0 mirrors row RW
+    __shared__ __attribute__((aligned(16))) uint32_t obuf[64 * OSW];  // doubles as the start-up tables
+    uint64_t *tab_off = reinterpret_cast<uint64_t *>(obuf);  // [64] sample offset of step 0 of round 0
+    uint32_t *tab_lo = obuf + 128, *tab_hi = obuf + 192;      // [64] each
+    static_assert(64 * OSW >= 256, "tables fit in obuf");
+
+    const int lane = lane_id();
+    const uint64_t g = (uint64_t)blockIdx.x * 64u + lane;
+    const bool active = g < G.total_waves;
+    const uint32_t k = G.k;
+
+    uint32_t len = 0, n = 0;
+    uint64_t S = 1, ooff = 0;
+    if (active) {
+        const WaveRef r = locate(G, g);
+        len = r.len;
+        ooff = r.sample_off;
+        S = wave_off[g] + 1u;
+        n = wave_words[g];
+    }
+    // start delay: step u of every round sits u*2 bytes past a T*2-byte boundary
+    const uint32_t phi = active ? (uint32_t)((((uintptr_t)out >> 1) + ooff) & (uint64_t)(T - 1)) : 0u;
+    tab_off[lane] = ooff - phi;
+    tab_lo[lane] = phi;
+    tab_hi[lane] = phi + len;
+    const uint32_t steps = wave_max_u32(len + phi);
+    const uint32_t lo_max = wave_max_u32(phi);
+    const uint32_t hi_min = ~wave_max_u32(~(phi + len));
+    wave_sync();
+    uint64_t wo_off[PPS];  // write-out constants: piece p of stream st_i, i = 0..PPS-1
+    uint32_t wo_lo[PPS], wo_hi[PPS];
+#pragma unroll
+    for (int i = 0; i < PPS; ++i) {
+        const int st = i * SPI + lane / PPS, p = lane % PPS;
+        wo_off[i] = tab_off[st] + 8u * (uint32_t)p;
+        wo_lo[i] = tab_lo[st];
+        wo_hi[i] = tab_hi[st];
+    }
+    wave_sync();
+
+    const uint64_t A = (S & ~(uint64_t)(RW - 1)) - (uint64_t)RW;  // s0 in [RW, 2 RW)
+    const uint32_t s0 = (uint32_t)(S - A);
+    const uint32_t endw = s0 + n;
+    uint32_t flw = s0 & ~(uint32_t)(LW - 1);
+    const bool in_vec_ok = ((uintptr_t)in & 15u) == 0;
+    uint32_t *myring = ring + lane;
+    typedef uint16_t __attribute__((may_alias)) u16a;
+    u16a *myout = reinterpret_cast<u16a *>(obuf + lane * OSW);
+
+    auto load_piece = [&](uint4 (&v)[NV]) {
+        const uint64_t a = A + flw;
+        if (in_vec_ok && a + (uint32_t)LW <= in_words) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const uint4 *>(in + a + 4 * j);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                v[j].x = (a + 4 * j + 0 < in_words) ? in[a + 4 * j + 0] : 0u;
+                v[j].y = (a + 4 * j + 1 < in_words) ? in[a + 4 * j + 1] : 0u;
+                v[j].z = (a + 4 * j + 2 < in_words) ? in[a + 4 * j + 2] : 0u;
+                v[j].w = (a + 4 * j + 3 < in_words) ? in[a + 4 * j + 3] : 0u;
+            }
+        }
+    };
+    auto store_piece = [&](const uint4 (&v)[NV]) {
+        const uint32_t r0 = (uint32_t)RW - (flw & (uint32_t)(RW - 1));
+        uint32_t *dst = myring + r0 * 64u;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            dst[-(4 * j + 0) * 64] = v[j].x; dst[-(4 * j + 1) * 64] = v[j].y;
+            dst[-(4 * j + 2) * 64] = v[j].z; dst[-(4 * j + 3) * 64] = v[j].w;
+        }
+        if (r0 == (uint32_t)RW) myring[0] = v[0].x;
+        flw += (uint32_t)LW;
+    };
+
+    uint32_t Q = 0u - 32u * s0;  // minus the bit position (relative to A)
+    // Q_need / Q_issue: positions (in Q units, Q decreases) at which this lane must have /
+    // would like to have its next piece; 0x80000000 apart from Q means "never" (stream exhausted)
+    uint32_t Q_need, Q_issue;
+    auto set_limits = [&]() {
+        // avail = flw - cw < X  <=>  cw > flw - X  <=>  Q <= ~(32 * (flw - X + 1) - 1) ... kept simple:
+        // cw = (~Q) >> 5, so cw >= c  <=>  ~Q >= 32 c  <=>  Q <= ~(32 c)
+        const bool more = flw < endw;
+        Q_need = more ? ~(32u * (flw - NEED_AT + 1u)) : Q - 0x7fffffffu;
+        Q_issue = more ? ~(32u * (flw - ISSUE_AT)) : Q - 0x7fffffffu;
+    };
+    auto sync_refill = [&]() {  // serve every lane that is (nearly) dry, waiting for the data
+        for (;;) {
+            const uint32_t avail = (flw - ((~Q) >> 5)) & WMASK;
+            const bool more = flw < endw;
+            if (!__any(more && avail < NEED_AT)) break;
+            if (more && avail <= (uint32_t)(RW - LW) && !(G.dbg & 2u)) {
+                uint4 v[NV];
+                load_piece(v);
+                store_piece(v);
+            } else if (more && avail <= (uint32_t)(RW - LW)) {
+                flw += (uint32_t)LW;
+            }
+            wave_sync();
+        }
+    };
+
+    {   // start-up: the piece that holds word s0 and as many more as fit
+        uint4 v[NV];
+        for (int i = 0; i < RW / LW; ++i) {
+            if (__ballot(flw < endw && flw + (uint32_t)LW <= s0 + (uint32_t)RW) == 0) break;
+            if (flw < endw && flw + (uint32_t)LW <= s0 + (uint32_t)RW) {
+                if (!(G.dbg & 2u)) { load_piece(v); store_piece(v); } else flw += (uint32_t)LW;
+            }
+        }
+        wave_sync();
+    }
+    int32_t acc = 0;
+
+    auto decode_group = [&](auto first_tag, int tg) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+#pragma unroll
+        for (int u = 0; u < GS; ++u) {
+            const uint32_t row = __builtin_amdgcn_ubfe(Q, 5u, (uint32_t)LOG_RW);
+            const uint32_t *wp = myring + row * 64u;
+            const uint32_t lo = wp[0], hi = wp[64];
+            const uint32_t win = __builtin_amdgcn_alignbit(hi, lo, Q);
+            const uint32_t q = (uint32_t)__builtin_clz(win);  // win == 0 only past the end of a corrupt stream
+            const bool esc = win < (1u << 24);
+            const uint32_t kk = esc ? 16u : k;
+            const uint32_t used = q + kk + 1u;
+            const uint32_t rem = __builtin_amdgcn_ubfe(win, 32u - used, kk);
+            const uint32_t z = (q << kk) + rem;  // escape: 8 << 16 stays above bit 15
+            const int32_t d = (int32_t)(z >> 1) ^ -(int32_t)(z & 1u);
+            if (FIRST) {
+                const bool act = (uint32_t)(tg + u) >= phi;
+                acc = act ? acc + d : acc;
+                Q = act ? Q - used : Q;
+            } else {
+                acc += d;
+                Q -= used;
+            }
+            myout[tg + u] = (uint16_t)acc;
+        }
+    };
+
+    auto write_out = [&](uint32_t t0) {
+        if (G.dbg & 1u) return;
+        if (t0 >= lo_max && t0 + T <= hi_min) {  // interior round: whole aligned lines only
+#pragma unroll
+            for (int i = 0; i < PPS; ++i) {
+                const int st = i * SPI + lane / PPS, p = lane % PPS;
+                const uint4 v = *reinterpret_cast<const uint4 *>(obuf + st * OSW + 4 * p);
+                *reinterpret_cast<uint4 *>(out + wo_off[i] + t0) = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PPS; ++i) {
+                const int st = i * SPI + lane / PPS, p = lane % PPS;
+                const uint32_t tpos = t0 + 8u * (uint32_t)p;  // step index of the piece's first sample
+                if (tpos + 8u > wo_lo[i] && tpos < wo_hi[i]) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(obuf + st * OSW + 4 * p);
+                    int16_t *dst = out + wo_off[i] + t0;
+                    if (tpos >= wo_lo[i] && tpos + 8u <= wo_hi[i]) {
+                        *reinterpret_cast<uint4 *>(dst) = v;
+                    } else {
+                        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (tpos + (uint32_t)j >= wo_lo[i] && tpos + (uint32_t)j < wo_hi[i])
+                                dst[j] = (int16_t)(w[j >> 1] >> (16 * (j & 1)));
+                    }
+                }
+            }
+        }
+    };
+
+    // round 0 (start delays; synchronous refills; runs once)
+    if (steps > 0) {
+#pragma unroll 1
+        for (int tg = 0; tg < T; tg += GS) {
+            sync_refill();
+            decode_group(std::true_type{}, tg);
+        }
+        wave_sync();
+        write_out(0);
+        wave_sync();
+    }
+
+    // steady state
+    uint4 pv[NV];        // piece in flight
+    bool pneed = false;  // this lane has one in flight
+    bool pend = false;   // some lane has (wave uniform)
+    set_limits();
+    for (uint32_t t0 = T; t0 < steps; t0 += T) {
+#pragma unroll 1
+        for (int tg = 0; tg < T; tg += GS) {
+            // refill policy: one signed compare per test (positions are mod 2^32)
+            if (pend && __any((int32_t)(Q - Q_need) <= 0)) {
+                if (pneed) { if (!(G.dbg & 2u)) store_piece(pv); else flw += (uint32_t)LW; }
+                pneed = false; pend = false;
+                wave_sync();
+                set_limits();
+            }
+            if (!pend) {
+                if (__any((int32_t)(Q - Q_need) <= 0)) { sync_refill(); set_limits(); }
+                if (__any((int32_t)(Q - Q_issue) <= 0)) {
+                    const uint32_t avail = (flw - ((~Q) >> 5)) & WMASK;
+                    pneed = (flw < endw) && avail <= (uint32_t)(RW - LW);
+                    if (pneed && !(G.dbg & 2u)) load_piece(pv);
+                    pend = true;
+                }
+            }
+            decode_group(std::false_type{}, tg);
+        }
+        wave_sync();
+        if (pend) {  // commit before this round's stores are issued
+            if (pneed) { if (!(G.dbg & 2u)) store_piece(pv); else flw += (uint32_t)LW; }
+            pneed = false; pend = false;
+            wave_sync();
+            set_limits();
+        }
+        write_out(t0);
+        wave_sync();
+    }
+}
+
 // ---------------------------------------------------------------------------
 // launchers (host side, same translation unit so that <<<>>> stays in HIP code)
 // ---------------------------------------------------------------------------
@@ -568,6 +1360,26 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
         case 0: k_decode_simple<<<nb, 64, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_out); break;
         case 2: k_decode_lanes<64, 32><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
         case 3: k_decode_lanes<128, 64><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
+        case 4: k_decode_lanes2<64, 32, 32><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
+        case 5: k_decode_lanes2<32, 16, 32><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
+        case 6: k_decode_lanes2<32, 16, 16><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
+        case 7: k_decode_lanes2<64, 16, 16><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
+        case 8: k_decode_lanes2<32, 16, 64><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
+        case 9: k_decode_lanes3<32, 16, 32, false><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
+        case 10: k_decode_lanes3<64, 32, 32, false><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
+        case 11: k_decode_lanes3<64, 32, 32, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
+        case 12: k_decode_lanes3<64, 32, 64, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
+        case 13: k_decode_lanes3<32, 16, 32, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
+        case 14: k_decode_lanes3<32, 16, 64, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
+        case 15: k_decode_lanes4<64, 32, 32><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
+        case 16: k_decode_lanes4<64, 16, 32><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
+        case 17: k_decode_lanes4<64, 32, 64><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
+        case 18: k_decode_lanes4<64, 16, 64><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
+        case 19: k_decode_lanes5<32, 8, 64, 8><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
+        case 20: k_decode_lanes5<32, 16, 64, 8><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
+        case 21: k_decode_lanes5<64, 16, 64, 16><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
+        case 22: k_decode_lanes5<64, 32, 64, 16><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
+        case 23: k_decode_lanes5<32, 8, 32, 8><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
         default: k_decode_lanes<64, 64><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
     }
     mark(ev, 2, s);

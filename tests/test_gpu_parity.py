@@ -34,7 +34,7 @@ def gpu_encode(ctx, plan, x):
     return enc, *enc.to_numpy()
 
 
-IMPLS = [0, 1, 2, 3]
+IMPLS = [0, 1, 11, 16, 19, 20, 21, 22, 23]
 
 
 # --------------------------------------------------------------------------- golden
@@ -52,7 +52,7 @@ def test_golden_batch_api(ctx, O, golden, name):
         ctx.set_option("decode_impl", impl)
         y = plan.decode(enc).cpu().numpy()
         assert np.array_equal(y, x), f"GPU decode (impl {impl}) differs"
-    ctx.set_option("decode_impl", 1)
+    ctx.set_option("decode_impl", 21)
 
 
 @pytest.mark.parametrize("name", ["kat_docs", "config1_one_chunk", "leftover_20877", "uniform_default",
@@ -130,7 +130,7 @@ def test_random_vs_oracle(ctx, O, n_chunks, chunk_samples, L, k, kind):
         ctx.set_option("decode_impl", impl)
         y = plan.decode(enc).cpu().numpy()
         assert np.array_equal(y, x), f"impl {impl}"
-    ctx.set_option("decode_impl", 1)
+    ctx.set_option("decode_impl", 21)
     # cross direction: oracle-encoded stream decoded on the GPU
     enc2 = type(enc)(dev(ctx, ref_w.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), ref_w.size)
     assert np.array_equal(plan.decode(enc2).cpu().numpy(), x)
@@ -157,7 +157,7 @@ def test_ragged_mixed_waveform_lengths(ctx, O):
     for impl in IMPLS:
         ctx.set_option("decode_impl", impl)
         assert np.array_equal(plan.decode(enc).cpu().numpy(), x)
-    ctx.set_option("decode_impl", 1)
+    ctx.set_option("decode_impl", 21)
 
 
 def test_decode_chunks_in_arbitrary_order(ctx, O):
@@ -207,7 +207,7 @@ def test_corrupt_stream_is_rejected_not_crashed(ctx, O):
             with pytest.raises(dr.DeltaRiceError) as e:
                 plan.decode(enc)
             assert e.value.status == 4
-    ctx.set_option("decode_impl", 1)
+    ctx.set_option("decode_impl", 21)
     with pytest.raises(dr.DeltaRiceError):
         ctx.filter_chunk(w[:-1], opts, reverse=True)
 

@@ -24,6 +24,7 @@ struct drx_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int decode_impl = 21;  // see launch_decode(); 0 = simple reference kernel
+    int encode_impl = 1;  // 1: single pass with look-back (k_encode_fused), 0: size pass + scan + pack pass
     int profile = 0;      // bracket kernels with HIP events (drx_plan_last_timings)
     uint32_t debug_flags = 0;  // Geom::dbg
     std::string last_error;
@@ -45,6 +46,7 @@ struct drx_plan {
     uint32_t *d_wave_rel = nullptr;    // encode: header position relative to chunk start
     uint64_t *d_wave_off = nullptr;    // decode: absolute header position
     uint64_t *d_chunk_words = nullptr;
+    uint64_t *d_scan = nullptr;        // look-back state of the single-pass encoder + ticket
     DevStatus *d_status = nullptr;
     DevStatus *h_status = nullptr;  // pinned
     bool last_was_encode = false;
@@ -166,6 +168,11 @@ drx_status drx_ctx_set_option(drx_ctx *c, const char *key, int64_t value) {
         c->decode_impl = (int)value;
         return DRX_OK;
     }
+    if (!strcmp(key, "encode_impl")) {
+        if (value < 0 || value > 1) return DRX_ERR_ARG;
+        c->encode_impl = (int)value;
+        return DRX_OK;
+    }
     if (!strcmp(key, "debug_flags")) {
         c->debug_flags = (uint32_t)value;
         return DRX_OK;
@@ -185,6 +192,7 @@ static void plan_free(drx_plan *p) {
     if (p->d_wave_rel) (void)hipFree(p->d_wave_rel);
     if (p->d_wave_off) (void)hipFree(p->d_wave_off);
     if (p->d_chunk_words) (void)hipFree(p->d_chunk_words);
+    if (p->d_scan) (void)hipFree(p->d_scan);
     if (p->d_status) (void)hipFree(p->d_status);
     if (p->h_status) (void)hipHostFree(p->h_status);
     for (hipEvent_t e : p->ev) if (e) (void)hipEventDestroy(e);
@@ -198,6 +206,7 @@ static drx_status plan_alloc(drx_ctx *ctx, drx_plan *p) {
     DRX_HIP(ctx, hipMalloc((void **)&p->d_wave_rel, W * sizeof(uint32_t)));
     DRX_HIP(ctx, hipMalloc((void **)&p->d_wave_off, W * sizeof(uint64_t)));
     DRX_HIP(ctx, hipMalloc((void **)&p->d_chunk_words, (p->G.n_chunks + 1) * sizeof(uint64_t)));
+    DRX_HIP(ctx, hipMalloc((void **)&p->d_scan, (W + 2) * sizeof(uint64_t)));
     DRX_HIP(ctx, hipMalloc((void **)&p->d_status, sizeof(DevStatus)));
     DRX_HIP(ctx, hipHostMalloc((void **)&p->h_status, sizeof(DevStatus), hipHostMallocDefault));
     memset(p->h_status, 0, sizeof(DevStatus));
@@ -305,9 +314,13 @@ drx_status drx_encode(drx_plan *p, const int16_t *d_in, uint32_t *d_out, uint64_
     drx_ctx *ctx = p->ctx;
     DRX_HIP(ctx, hipSetDevice(ctx->device));
     DRX_HIP(ctx, hipMemsetAsync(p->d_status, 0, sizeof(DevStatus), ctx->stream));
-    DRX_HIP(ctx, launch_encode(p->G, d_in, d_out, out_cap_words, d_chunk_word_off, p->d_wave_words,
-                               p->d_wave_rel, p->d_chunk_words, p->d_status, ctx->profile ? p->ev : nullptr,
-                               ctx->stream));
+    if (ctx->encode_impl == 1)
+        DRX_HIP(ctx, launch_encode_fused(p->G, d_in, d_out, out_cap_words, d_chunk_word_off, p->d_wave_words,
+                                         p->d_scan, p->d_status, ctx->profile ? p->ev : nullptr, ctx->stream));
+    else
+        DRX_HIP(ctx, launch_encode(p->G, d_in, d_out, out_cap_words, d_chunk_word_off, p->d_wave_words,
+                                   p->d_wave_rel, p->d_chunk_words, p->d_status, ctx->profile ? p->ev : nullptr,
+                                   ctx->stream));
     p->ev_valid = ctx->profile != 0;
     p->last_was_encode = true;
     return DRX_OK;
@@ -346,6 +359,7 @@ drx_status drx_plan_finish(drx_plan *p, uint64_t *total_words) {
     DRX_HIP(ctx, hipMemcpyAsync(p->h_status, p->d_status, sizeof(DevStatus), hipMemcpyDeviceToHost, ctx->stream));
     DRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (total_words) *total_words = p->h_status->total_words;
+    if (p->h_status->err & kErrInternal) return fail(ctx, DRX_ERR_DEVICE, "encoder look-back timed out (internal error)");
     if (p->h_status->err & kErrCorrupt) return fail(ctx, DRX_ERR_CORRUPT, "encoded input failed header-chain validation");
     if (p->h_status->err & kErrCapacity)
         return fail(ctx, DRX_ERR_CAPACITY, "encoded batch needs %llu words", (unsigned long long)p->h_status->total_words);

@@ -37,10 +37,15 @@ struct DevStatus {
 
 constexpr uint32_t kErrCapacity = 1u;
 constexpr uint32_t kErrCorrupt = 2u;
+constexpr uint32_t kErrInternal = 4u;
 
 hipError_t launch_encode(const Geom &G, const int16_t *d_in, uint32_t *d_out, uint64_t out_cap,
                          uint64_t *d_chunk_word_off, uint32_t *d_wave_words, uint32_t *d_wave_rel,
                          uint64_t *d_chunk_words, DevStatus *d_status, hipEvent_t *ev, hipStream_t s);
+
+hipError_t launch_encode_fused(const Geom &G, const int16_t *d_in, uint32_t *d_out, uint64_t out_cap,
+                               uint64_t *d_chunk_word_off, uint32_t *d_wave_words, uint64_t *d_scan,
+                               DevStatus *d_status, hipEvent_t *ev, hipStream_t s);
 
 hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                          const uint64_t *d_chunk_word_off, int16_t *d_out, uint64_t *d_wave_off,

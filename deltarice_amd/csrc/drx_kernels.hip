@@ -313,6 +313,325 @@ __global__ __launch_bounds__(256) void k_encode_pack(Geom G, const int16_t *__re
 }
 
 // ---------------------------------------------------------------------------
+// encode, single pass
+// ---------------------------------------------------------------------------
+// One wavefront per waveform, one read of the input, one write of the output:
+//   tile loop   8 consecutive samples per lane (one 16-byte load), residuals / zig-zag /
+//               code lengths in packed 16-bit math (v_pk_*: two samples per instruction),
+//               DPP prefix scan of the lanes' bit counts -> bit offset of every code,
+//               codes OR-ed (ds_or_b32) into the waveform's own LDS buffer;
+//   look-back   the waveform's size n_i is known only now; its position in the packed
+//               output is the prefix sum over all earlier waveforms (src/deltaRice.c:427-432
+//               does this with a serial memcpy loop).  Decoupled look-back over 8-byte
+//               {status, value} words, one per waveform, written and polled with agent-scope
+//               relaxed atomics (the word is its own flag).  Waveform indices are handed
+//               out by an atomic ticket, so every predecessor a wave may wait for is already
+//               running: no dependence on dispatch order or placement;
+//   copy out    LDS -> HBM, 256 contiguous bytes per store instruction.
+// A waveform whose code does not fit the LDS buffer (incompressible data, very long
+// waveforms) finishes the size count without emitting, does the same look-back, and is then
+// re-encoded tile by tile straight to its final position (second read of its samples).
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+typedef int16_t i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 as_u16x2(uint32_t x) { return __builtin_bit_cast(u16x2, x); }
+__device__ __forceinline__ i16x2 as_i16x2(uint32_t x) { return __builtin_bit_cast(i16x2, x); }
+__device__ __forceinline__ uint32_t as_u32(u16x2 x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ u16x2 splat(uint32_t v) { return (u16x2){(uint16_t)v, (uint16_t)v}; }
+
+// inclusive prefix sum over the 64 lanes (DPP: row shifts, then row broadcasts)
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+// Packed code parameters of the 8 samples a lane holds as 4 dwords (low half = earlier sample).
+//   nb  code length, r  payload bits (k low bits of z, or all 16 for an escape),
+//   kk  payload width = position of the terminating '1' above the payload.
+struct PackedCodes { uint32_t nb[4], r[4], kk[4]; };
+
+// x[j]: samples 2j, 2j+1; xprev: dword whose HIGH half is the sample just before x[0]'s low half.
+__device__ __forceinline__ void packed_codes(const uint32_t x[4], uint32_t xprev, uint32_t k, PackedCodes &c) {
+    const u16x2 kv = splat(k), kp1 = splat(k + 1u), c16k = splat(16u - k);
+    const u16x2 mlo = splat((1u << k) - 1u), mdelta = splat(0xffffu - ((1u << k) - 1u));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t before = __builtin_amdgcn_alignbit(x[j], j ? x[j - 1] : xprev, 16);  // samples 2j-1, 2j
+        const i16x2 d = as_i16x2(x[j]) - as_i16x2(before);                                   // :51-63, mod 2^16
+        const u16x2 z = __builtin_bit_cast(u16x2, (i16x2)(d << (int16_t)1)) ^
+                        __builtin_bit_cast(u16x2, (i16x2)(d >> (int16_t)15));                // zig-zag :207-211
+        const u16x2 qc = __builtin_elementwise_min((u16x2)(z >> kv), splat(8u));            // min(q, 8)
+        const u16x2 e = qc >> (uint16_t)3;                                                   // 1 = escape (:215)
+        c.nb[j] = as_u32(e * c16k + (qc + kp1));   // q+1+k, or 8+1+16
+        c.r[j] = as_u32(z & (e * mdelta + mlo));   // z & (M-1), or z
+        c.kk[j] = as_u32(e * c16k + kv);           // k, or 16
+    }
+}
+
+constexpr uint32_t kEncCapWords = 2048;  // LDS words per waveform buffer (8 KB): 9.3 bits/sample at L = 7000
+constexpr uint64_t kScanAgg = 1ull << 62, kScanPrefix = 2ull << 62, kScanValMask = (1ull << 62) - 1ull;
+
+// Loads this lane's 8 samples of the tile as 4 dwords; returns the number that exist.
+__device__ __forceinline__ int load8_dwords(const int16_t *__restrict__ x, uint32_t len, uint32_t t0, int lane,
+                                            bool vec_ok, uint32_t w[4]) {
+    const uint32_t i0 = t0 + 8u * (uint32_t)lane;
+    const int nv = (i0 >= len) ? 0 : (int)((len - i0) < 8u ? (len - i0) : 8u);
+    if (vec_ok && nv == 8) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(x + i0);
+        w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t a = (2 * j < nv) ? (uint32_t)(uint16_t)x[i0 + 2 * j] : 0u;
+            const uint32_t b = (2 * j + 1 < nv) ? (uint32_t)(uint16_t)x[i0 + 2 * j + 1] : 0u;
+            w[j] = a | (b << 16);
+        }
+    }
+    return nv;
+}
+
+// Bits of this lane's nv codes (nv == 8 for every lane of a full tile).
+template <bool FULL>
+__device__ __forceinline__ uint32_t lane_tile_bits(const PackedCodes &c, int nv) {
+    if (FULL) {
+        const u16x2 s = as_u16x2(c.nb[0]) + as_u16x2(c.nb[1]) + as_u16x2(c.nb[2]) + as_u16x2(c.nb[3]);
+        const uint32_t v = as_u32(s);
+        return (v & 0xffffu) + (v >> 16);
+    }
+    uint32_t bits = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t n0 = (2 * j < nv) ? (c.nb[j] & 0xffffu) : 0u;
+        const uint32_t n1 = (2 * j + 1 < nv) ? (c.nb[j] >> 16) : 0u;
+        bits += n0 + n1;
+    }
+    return bits;
+}
+
+// ORs this lane's codes into LDS.  pb = 8 * (byte address of the buffer's word 0) + bit position of
+// the lane's first code: (pb >> 3) & ~3 is the LDS byte address of the word holding that bit.
+template <bool FULL>
+__device__ __forceinline__ void emit_tile(const PackedCodes &c, int nv, uint32_t pb) {
+    typedef uint32_t __attribute__((address_space(3))) lds_u32;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (FULL || j < nv) {
+            const uint32_t sh = (j & 1) ? 16u : 0u;
+            const uint32_t n = (j & 1) ? (c.nb[j >> 1] >> 16) : (c.nb[j >> 1] & 0xffffu);
+            const uint32_t r = (j & 1) ? (c.r[j >> 1] >> 16) : (c.r[j >> 1] & 0xffffu);
+            const uint32_t kk = (j & 1) ? (c.kk[j >> 1] >> 16) : (c.kk[j >> 1] & 0xffffu);
+            (void)sh;
+            const uint64_t code = (uint64_t)((1u << kk) | r);   // terminator + payload; the leading zeros are implicit
+            const uint64_t v = code << (64u - (pb & 31u) - n);  // code left-aligned at bit (pb & 31) of a 64-bit window
+            lds_u32 *w = (lds_u32 *)(uintptr_t)((pb >> 3) & ~3u);
+            __hip_atomic_fetch_or(w, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((uint32_t)v) __hip_atomic_fetch_or(w + 1, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            pb += n;
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t lds_addr(const uint32_t *p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t *)p;
+}
+
+constexpr int kEncWaves = 8;  // waveforms (wavefronts) per workgroup = per ticket
+
+__global__ __launch_bounds__(64 * kEncWaves) void k_encode_fused(Geom G, const int16_t *__restrict__ in,
+                                                      uint32_t *__restrict__ out, uint64_t out_cap,
+                                                      uint64_t *__restrict__ chunk_word_off,
+                                                      uint32_t *__restrict__ wave_words,
+                                                      uint64_t *__restrict__ scan_state,
+                                                      uint32_t *__restrict__ ticket, DevStatus *st) {
+    __shared__ __attribute__((aligned(16))) uint32_t buf_all[kEncWaves][kEncCapWords + 8];
+    __shared__ uint32_t s_ticket;
+    __shared__ uint64_t s_mine[kEncWaves];
+    __shared__ uint64_t s_excl;
+    const int lane = lane_id();
+    uint32_t *buf = buf_all[threadIdx.x >> 6];
+    const uint32_t buf_bits = lds_addr(buf) * 8u;  // LDS is 160 KB: bit addresses fit easily
+
+    // Waveform indices by ticket: every lower index is already owned by a running (or finished)
+    // wave.  One ticket per workgroup of kEncWaves waveforms: a single global counter serves
+    // about 88 atomics per microsecond (a ticket per waveform made the whole kernel run at
+    // exactly that rate: 1M waveforms in 11.9 ms).
+    if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint64_t g = (uint64_t)s_ticket * kEncWaves + (threadIdx.x >> 6);
+    const bool live = g < G.total_waves;  // the last workgroup may be partial; its idle waves still join the barriers
+
+    for (int i = lane; i < (int)(kEncCapWords + 8) / 4; i += 64) reinterpret_cast<uint4 *>(buf)[i] = make_uint4(0, 0, 0, 0);
+    WaveRef r = locate(G, live ? g : 0);
+    if (!live) { r.len = 0; r.idx = 1; }  // an idle wave of the last workgroup: nothing to encode, nothing to add
+    const int16_t *x = in + r.sample_off;
+    const bool vec_ok = ((uintptr_t)x & 15u) == 0;
+    const uint32_t k = G.k;
+    wave_sync();
+
+    // ---- pass over the samples: emit into LDS while it fits, count bits always ----
+    // The next tile's load is issued before the current tile is processed, so that the HBM
+    // round trip (PMC: 76 % of the wave cycles were s_waitcnt without this) overlaps the packing.
+    uint64_t P = 0;        // bits so far (wave uniform)
+    bool fits = true;      // everything so far is in buf (wave uniform)
+    uint32_t carry = 0;    // dword whose high half is the sample before the tile (x[-1] := 0, :53-54)
+    constexpr int kAhead = 2;  // tiles in flight: ~6 K cycles of packing cover one HBM round trip
+    uint32_t wq[kAhead][4];
+    int nvq[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+        nvq[u] = 0;
+        if ((uint32_t)u * kTile < r.len) nvq[u] = load8_dwords(x, r.len, (uint32_t)u * kTile, lane, vec_ok, wq[u]);
+    }
+    auto process_tile = [&](const uint32_t (&w)[4], int nv, uint32_t t0) {
+        uint32_t xprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[3], 0x138, 0xf, 0xf, false);  // wave_shr:1
+        if (lane == 0) xprev = carry;
+        carry = (uint32_t)__builtin_amdgcn_readlane((int)w[3], 63);
+        PackedCodes c;
+        packed_codes(w, xprev, k, c);
+        const bool full = t0 + kTile <= r.len;  // wave uniform: no lane needs masking
+        const uint32_t lane_bits = full ? lane_tile_bits<true>(c, 8) : lane_tile_bits<false>(c, nv);
+        const uint32_t incl = wave_incl_scan_dpp(lane_bits);
+        const uint32_t tile_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (fits && ((P + tile_bits + 31u) >> 5) < (uint64_t)kEncCapWords) {
+            const uint32_t pb = buf_bits + (uint32_t)P + incl - lane_bits;
+            if (full) emit_tile<true>(c, 8, pb); else emit_tile<false>(c, nv, pb);
+        } else {
+            fits = false;
+        }
+        P += tile_bits;
+    };
+#pragma unroll 1
+    for (uint32_t t0 = 0; t0 < r.len; t0 += kAhead * kTile) {
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            const uint32_t tu = t0 + (uint32_t)u * kTile;
+            if (tu < r.len) {
+                const uint32_t w[4] = {wq[u][0], wq[u][1], wq[u][2], wq[u][3]};
+                const int nv = nvq[u];
+                const uint32_t tn = tu + kAhead * kTile;
+                if (tn < r.len) nvq[u] = load8_dwords(x, r.len, tn, lane, vec_ok, wq[u]);
+                process_tile(w, nv, tu);
+            }
+        }
+    }
+    const uint32_t n = (uint32_t)((P + 31u) >> 5);  // payload words n_i
+    wave_sync();
+
+    // ---- position of this waveform ----
+    // Prefix sum over v_j = 1 + n_j (+1 for a chunk's first waveform).  The kEncWaves waveforms of
+    // this workgroup are summed through LDS; wave 0 then runs a decoupled look-back over ONE entry
+    // per workgroup, 128 entries per poll.  (One entry per waveform and 64 per poll capped the whole
+    // encoder at ~64 waveforms per memory round trip, i.e. ~9 ms for 1M waveforms: a predecessor's
+    // prefix is published one round trip after its aggregate, so the frontier of known prefixes
+    // advances by at most one window per round trip.)
+    const uint64_t mine = live ? 1ull + n + (r.idx == 0 ? 1ull : 0ull) : 0ull;
+    const int wv = threadIdx.x >> 6;
+    if (lane == 0) s_mine[wv] = mine;
+    __syncthreads();
+    if (wv == 0) {
+        uint64_t block_sum = 0;
+#pragma unroll
+        for (int i = 0; i < kEncWaves; ++i) block_sum += s_mine[i];
+        const uint64_t T = s_ticket;
+        uint64_t excl_blk = 0;
+        if (T == 0) {
+            if (lane == 0) __hip_atomic_store(scan_state, kScanPrefix | block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(scan_state + T, kScanAgg | block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int64_t base = (int64_t)T - 1;
+            uint32_t spins = 0;
+            for (;;) {
+                // lane l looks at predecessors base-l (nearer) and base-64-l (farther)
+                const int64_t i0 = base - lane, i1 = base - 64 - lane;
+                uint64_t s0v = kScanPrefix, s1v = kScanPrefix;  // before the first workgroup: an empty prefix
+                if (i0 >= 0) s0v = __hip_atomic_load(scan_state + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (i1 >= 0) s1v = __hip_atomic_load(scan_state + i1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t st0 = (uint32_t)(s0v >> 62), st1 = (uint32_t)(s1v >> 62);
+                const uint64_t p0 = __ballot(st0 == 2u), z0 = __ballot(st0 == 0u);
+                const uint64_t p1 = __ballot(st1 == 2u), z1 = __ballot(st1 == 0u);
+                // position of the nearest prefix in the 128-entry window (0 = nearest predecessor)
+                const int fp = p0 ? __builtin_ctzll(p0) : (p1 ? 64 + __builtin_ctzll(p1) : 128);
+                const uint64_t near0 = fp >= 64 ? ~0ull : ((1ull << fp) - 1ull);
+                const uint64_t near1 = fp >= 128 ? ~0ull : (fp > 64 ? ((1ull << (fp - 64)) - 1ull) : 0ull);
+                if ((z0 & near0) | (z1 & near1)) {  // a nearer predecessor has not published yet
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 22)) {  // cannot happen with a zeroed scan_state; never hang the GPU
+                        if (lane == 0) atomicOr(&st->err, kErrInternal);
+                        break;
+                    }
+                    continue;
+                }
+                const uint64_t c0 = (lane <= fp) ? (s0v & kScanValMask) : 0ull;
+                const uint64_t c1 = (64 + lane <= fp) ? (s1v & kScanValMask) : 0ull;
+                excl_blk += wave_sum_u64(c0 + c1);
+                if (fp < 128) break;
+                base -= 128;
+            }
+            if (lane == 0)
+                __hip_atomic_store(scan_state + T, kScanPrefix | (excl_blk + block_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) s_excl = excl_blk;
+    }
+    __syncthreads();
+    uint64_t excl = s_excl;
+#pragma unroll
+    for (int i = 0; i < kEncWaves; ++i) excl += (i < wv) ? s_mine[i] : 0ull;
+    if (!live) return;
+    const uint64_t pos = excl + (r.idx == 0 ? 1ull : 0ull);  // this waveform's header word
+    if (lane == 0) {
+        wave_words[g] = n;
+        if (r.idx == 0) chunk_word_off[r.chunk] = excl;
+        if (g + 1 == G.total_waves) {
+            chunk_word_off[G.n_chunks] = excl + mine;
+            st->total_words = excl + mine;
+            if (excl + mine > out_cap) atomicOr(&st->err, kErrCapacity);
+        }
+    }
+    if (pos + 1u + n > out_cap) return;  // the last waveform raises kErrCapacity
+    if (lane == 0) {
+        out[pos] = n;                               // :379
+        if (r.idx == 0) out[pos - 1] = r.n_samples;  // chunk header, :415
+    }
+    uint32_t *__restrict__ outp = out + pos + 1;
+    if (fits) {
+        for (uint32_t i = lane; i < n; i += 64) outp[i] = buf[i];
+        return;
+    }
+
+    // ---- the code did not fit the LDS buffer: stream it tile by tile to its final position ----
+    for (int i = lane; i < (int)(kEncCapWords + 8) / 4; i += 64) reinterpret_cast<uint4 *>(buf)[i] = make_uint4(0, 0, 0, 0);
+    wave_sync();
+    P = 0;
+    carry = 0;
+    for (uint32_t t0 = 0; t0 < r.len; t0 += kTile) {
+        uint32_t w[4];
+        const int nv = load8_dwords(x, r.len, t0, lane, vec_ok, w);
+        uint32_t xprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[3], 0x138, 0xf, 0xf, false);
+        if (lane == 0) xprev = carry;
+        carry = (uint32_t)__shfl((int)w[3], 63);
+        PackedCodes c;
+        packed_codes(w, xprev, k, c);
+        const uint32_t lane_bits = lane_tile_bits<false>(c, nv);
+        const uint32_t incl = wave_incl_scan_dpp(lane_bits);
+        const uint32_t tile_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint64_t w0 = P >> 5;  // first staged word
+        emit_tile<false>(c, nv, buf_bits + (uint32_t)(P & 31u) + incl - lane_bits);
+        P += tile_bits;
+        wave_sync();
+        const uint32_t nfull = (uint32_t)((P >> 5) - w0);
+        for (uint32_t i = lane; i < nfull; i += 64) { outp[w0 + i] = buf[i]; buf[i] = 0; }
+        wave_sync();
+        if (nfull && lane == 0) { const uint32_t cw = buf[nfull]; buf[nfull] = 0; buf[0] = cw; }
+        wave_sync();
+    }
+    if ((P & 31u) && lane == 0) outp[P >> 5] = buf[0];
+}
+
+// ---------------------------------------------------------------------------
 // decode
 // ---------------------------------------------------------------------------
 
@@ -1328,6 +1647,24 @@ static inline unsigned blocks_for(uint64_t items, unsigned per_block) {
 
 static inline void mark(hipEvent_t *ev, int i, hipStream_t s) {
     if (ev) (void)hipEventRecord(ev[i], s);
+}
+
+// Single-pass encode (k_encode_fused).  d_scan: uint64[total_waves] + one uint32 ticket
+// word after it, zeroed here on the stream before every launch.
+hipError_t launch_encode_fused(const Geom &G, const int16_t *d_in, uint32_t *d_out, uint64_t out_cap,
+                               uint64_t *d_chunk_word_off, uint32_t *d_wave_words, uint64_t *d_scan,
+                               DevStatus *d_status, hipEvent_t *ev, hipStream_t s) {
+    if (G.total_waves == 0) return hipSuccess;
+    mark(ev, 0, s);
+    hipError_t e = hipMemsetAsync(d_scan, 0, (G.total_waves + 2) * sizeof(uint64_t), s);
+    if (e != hipSuccess) return e;
+    mark(ev, 1, s);
+    mark(ev, 2, s);
+    uint32_t *ticket = reinterpret_cast<uint32_t *>(d_scan + G.total_waves);
+    k_encode_fused<<<blocks_for(G.total_waves, kEncWaves), 64 * kEncWaves, 0, s>>>(G, d_in, d_out, out_cap, d_chunk_word_off,
+                                                                d_wave_words, d_scan, ticket, d_status);
+    mark(ev, 3, s);
+    return hipGetLastError();
 }
 
 // ev: optional 4 events recorded before / between / after the kernels (profiling).

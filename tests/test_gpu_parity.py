@@ -30,8 +30,17 @@ def dev(ctx, a):
 
 
 def gpu_encode(ctx, plan, x):
-    enc = plan.encode(dev(ctx, x.reshape(-1).view(np.int16)))
-    return enc, *enc.to_numpy()
+    """Encodes with both encoder implementations (single pass with look-back, and the
+    size/scan/pack passes), checks they agree, returns the default one's result."""
+    xd = dev(ctx, x.reshape(-1).view(np.int16))
+    ctx.set_option("encode_impl", 0)
+    enc0 = plan.encode(xd)
+    w0, off0 = enc0.to_numpy()
+    ctx.set_option("encode_impl", 1)
+    enc = plan.encode(xd)
+    w, off = enc.to_numpy()
+    assert np.array_equal(off, off0) and np.array_equal(w, w0), "encoder implementations disagree"
+    return enc, w, off
 
 
 IMPLS = [0, 1, 11, 16, 19, 20, 21, 22, 23]

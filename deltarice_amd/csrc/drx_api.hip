@@ -23,7 +23,8 @@ struct drx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    int decode_impl = 21;  // see launch_decode(); 0 = simple reference kernel
+    int decode_impl = 5;   // launch_decode(): 5 = walk fused into the staged kernel (default; uniform batches),
+                           // 1 = walk kernel + staged kernel, 2-4/6 = other ring geometries, 0 = simple kernel
     int encode_impl = 1;  // 1: single pass with look-back (k_encode_fused), 0: size pass + scan + pack pass
     int profile = 0;      // bracket kernels with HIP events (drx_plan_last_timings)
     uint32_t debug_flags = 0;  // Geom::dbg
@@ -164,7 +165,7 @@ void *drx_ctx_stream(const drx_ctx *c) { return c ? (void *)c->stream : nullptr;
 drx_status drx_ctx_set_option(drx_ctx *c, const char *key, int64_t value) {
     if (!c || !key) return DRX_ERR_ARG;
     if (!strcmp(key, "decode_impl")) {
-        if (value < 0 || value > 23) return DRX_ERR_ARG;
+        if (value < 0 || value > 6) return DRX_ERR_ARG;
         c->decode_impl = (int)value;
         return DRX_OK;
     }
@@ -334,8 +335,8 @@ drx_status drx_decode(drx_plan *p, const uint32_t *d_in, uint64_t in_words,
     DRX_HIP(ctx, hipMemsetAsync(p->d_status, 0, sizeof(DevStatus), ctx->stream));
     p->G.dbg = ctx->debug_flags;
     DRX_HIP(ctx, launch_decode(p->G, d_in, in_words, d_chunk_word_off, d_out, p->d_wave_off,
-                               p->d_wave_words, p->d_status, ctx->decode_impl, ctx->profile ? p->ev : nullptr,
-                               ctx->stream));
+                               p->d_wave_words, p->d_scan, p->d_status, ctx->decode_impl,
+                               ctx->profile ? p->ev : nullptr, ctx->stream));
     p->ev_valid = ctx->profile != 0;
     p->last_was_encode = false;
     return DRX_OK;

@@ -49,7 +49,8 @@ hipError_t launch_encode_fused(const Geom &G, const int16_t *d_in, uint32_t *d_o
 
 hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                          const uint64_t *d_chunk_word_off, int16_t *d_out, uint64_t *d_wave_off,
-                         uint32_t *d_wave_words, DevStatus *d_status, int impl, hipEvent_t *ev, hipStream_t s);
+                         uint32_t *d_wave_words, uint64_t *d_granules, DevStatus *d_status, int impl,
+                         hipEvent_t *ev, hipStream_t s);
 
 }  // namespace drx
 #endif

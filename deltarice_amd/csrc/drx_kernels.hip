@@ -636,12 +636,16 @@ __global__ __launch_bounds__(64 * kEncWaves) void k_encode_fused(Geom G, const i
 // ---------------------------------------------------------------------------
 
 // Header chain walk (:320-325) with validation; one lane per chunk.
-__global__ __launch_bounds__(64) void k_walk(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
-                                             const uint64_t *__restrict__ chunk_word_off,
-                                             uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
-                                             DevStatus *st) {
-    const uint64_t c = (uint64_t)blockIdx.x * 64u + threadIdx.x;
-    if (c >= G.n_chunks) return;
+// granules (optional): one 8-byte word per waveform, {valid:1 | n_i:31 | header position relative to
+// the chunk start:32}, stored with one agent-scope relaxed atomic each -- the word is its own flag
+// (it is zero until written), so a decoder wave in the SAME launch can consume waveform w of a
+// chunk while the walk of that chunk is still at waveform w+1.
+constexpr uint64_t kGranValid = 1ull << 63;
+
+__device__ __forceinline__ void walk_chunk(const Geom &G, uint64_t c, const uint32_t *__restrict__ in,
+                                           uint64_t in_words, const uint64_t *__restrict__ chunk_word_off,
+                                           uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
+                                           uint64_t *__restrict__ granules, DevStatus *st) {
     uint64_t base;
     uint32_t W, L, N;
     if (G.uniform) { base = c * G.u_n_waves; W = G.u_n_waves; L = G.u_wave_len; N = G.u_n_samples; }
@@ -649,7 +653,7 @@ __global__ __launch_bounds__(64) void k_walk(Geom G, const uint32_t *__restrict_
     const uint64_t begin = chunk_word_off[c];
     uint64_t end = chunk_word_off[c + 1];
     bool bad = false;
-    if (end > in_words || begin + 2 > end) { bad = true; end = begin; }
+    if (end > in_words || begin + 2 > end || end - begin > 0xffffffffull) { bad = true; end = begin; }
     if (!bad && in[begin] != N) bad = true;  // :306 totalNumberPoints
     uint64_t at = begin + 1;
     for (uint32_t w = 0; w < W; ++w) {
@@ -667,9 +671,21 @@ __global__ __launch_bounds__(64) void k_walk(Geom G, const uint32_t *__restrict_
         }
         wave_off[base + w] = here;
         wave_words[base + w] = n;
+        if (granules)
+            __hip_atomic_store(granules + base + w, kGranValid | ((uint64_t)n << 32) | (uint64_t)(uint32_t)(here - begin),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (!bad && at != end) bad = true;
     if (bad) atomicOr(&st->err, kErrCorrupt);
+}
+
+__global__ __launch_bounds__(64) void k_walk(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
+                                             const uint64_t *__restrict__ chunk_word_off,
+                                             uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
+                                             DevStatus *st) {
+    const uint64_t c = (uint64_t)blockIdx.x * 64u + threadIdx.x;
+    if (c >= G.n_chunks) return;
+    walk_chunk(G, c, in, in_words, chunk_word_off, wave_off, wave_words, nullptr, st);
 }
 
 // Straightforward lane-per-waveform decoder: global loads and 2-byte stores.
@@ -709,702 +725,45 @@ __global__ __launch_bounds__(64) void k_decode_simple(Geom G, const uint32_t *__
     }
 }
 
-// Staged lane-per-waveform decoder.
-//   RW   ring words per stream (power of two >= 64): compressed words live in LDS at
-//        ring[lane][word_index mod RW]; whole 128-byte lines (32 words) are loaded by
-//        8 lanes x 16 B each, 8 streams per wave instruction.
-//   T    samples decoded per round; after a round the 64 x T tile is written out with
-//        16-byte stores, 8 lanes covering T=64 samples (128 B) of one waveform.
-template <int RW, int T>
-__global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
-                                                     const uint64_t *__restrict__ wave_off,
-                                                     const uint32_t *__restrict__ wave_words,
-                                                     int16_t *__restrict__ out) {
-    constexpr int RS = RW + 1;     // ring row stride in words (odd: conflict-free for equal indices)
-    constexpr int OSW = T / 2 + 1; // output row stride in words (odd)
-    constexpr int PPS = T / 8;     // 16-byte pieces per stream per round
-    constexpr int SPI = 64 / PPS;  // streams per write-out iteration
-    __shared__ uint32_t ring[64 * RS];
-    __shared__ uint32_t obuf[64 * OSW];
-    __shared__ uint64_t tab_ooff[64];
-    __shared__ uint32_t tab_len[64];
-
-    const int lane = lane_id();
-    const uint64_t g = (uint64_t)blockIdx.x * 64u + lane;
-    const bool active = g < G.total_waves;
-    const uint32_t k = G.k;
-
-    uint32_t len = 0, n = 0;
-    uint64_t S = 0, ooff = 0;
-    if (active) {
-        const WaveRef r = locate(G, g);
-        len = r.len;
-        ooff = r.sample_off;
-        S = wave_off[g] + 1u;
-        n = wave_words[g];
-    }
-    tab_ooff[lane] = ooff;
-    tab_len[lane] = len;
-    const uint64_t A = S & ~(uint64_t)(RW - 1);   // ring-aligned base (word index): ring slot = (w - A) mod RW
-    const uint32_t s0 = (uint32_t)(S - A);        // first payload word, relative to A
-    const uint32_t endw = s0 + n;                  // one past the last payload word, relative
-    uint32_t flw = s0 & ~31u;                      // words loaded so far (whole 128-byte lines), relative
-    uint32_t rdw = s0;                             // next word to move into the window
-    const bool in_vec_ok = ((uintptr_t)in & 15u) == 0;
-    const uint32_t maxlen = wave_max_u32(len);
-    uint32_t *myring = ring + lane * RS;
-    typedef uint16_t __attribute__((may_alias)) u16a;
-    u16a *myout = reinterpret_cast<u16a *>(obuf + lane * OSW);
-
-    // Loads one more line for every stream that has room for it and data left.
-    auto top_up = [&]() {
-        for (;;) {
-            // room: the line would overwrite words [flw-RW, flw-RW+32), all of which must be consumed
-            const bool need = (flw < endw) && (flw <= rdw || flw - rdw + 32u <= (uint32_t)RW);
-            const uint64_t mask = __ballot(need);
-            if (mask == 0) break;
-            const uint64_t nx = A + flw;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int s = i * 8 + (lane >> 3), p = lane & 7;
-                const uint64_t nxs = __shfl(nx, s);
-                if ((mask >> s) & 1u) {
-                    const uint64_t a = nxs + 4u * (uint32_t)p;
-                    uint4 v;
-                    if (in_vec_ok && a + 4u <= in_words) {
-                        v = *reinterpret_cast<const uint4 *>(in + a);
-                    } else {
-                        v.x = (a + 0u < in_words) ? in[a + 0u] : 0u;
-                        v.y = (a + 1u < in_words) ? in[a + 1u] : 0u;
-                        v.z = (a + 2u < in_words) ? in[a + 2u] : 0u;
-                        v.w = (a + 3u < in_words) ? in[a + 3u] : 0u;
-                    }
-                    uint32_t *dst = ring + s * RS + ((uint32_t)nxs & (uint32_t)(RW - 1)) + 4 * p;
-                    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-                }
-            }
-            if (need) flw += 32u;
-            wave_sync();
-        }
-    };
-
-    wave_sync();
-    top_up();
-    // window: bits [o', ...) of the pair (hi, lo) with o in [1, 32]; o = 32 means "lo starts now"
-    uint32_t hi = 0, lo = myring[rdw & (RW - 1)];
-    ++rdw;
-    uint32_t o = 32;
-    int32_t acc = 0;
-
-    for (uint32_t t0 = 0; t0 < maxlen; t0 += T) {
-#pragma unroll 1
-        for (int tg = 0; tg < T; tg += 4) {
-            // a group of 4 samples consumes at most 4 words
-            if (__any((flw - rdw < 5u) && (flw < endw))) top_up();
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t win = __builtin_amdgcn_alignbit(hi, lo, 32u - o);
-                uint32_t q = (uint32_t)__clz((int)win);
-                const bool esc = q >= 8u;  // valid streams have q <= 8
-                q = esc ? 8u : q;
-                const uint32_t pl = esc ? 16u : k;
-                const uint32_t used = q + 1u + pl;
-                const uint32_t rem = __builtin_amdgcn_ubfe(win, 32u - used, pl);
-                const uint32_t z = esc ? rem : ((q << k) + rem);
-                acc += (int32_t)(z >> 1) ^ -(int32_t)(z & 1u);
-                myout[tg + u] = (uint16_t)acc;
-                o += used;
-                if (o > 32u) {
-                    o -= 32u;
-                    hi = lo;
-                    lo = myring[rdw & (RW - 1)];
-                    ++rdw;
-                }
-            }
-        }
-        wave_sync();
-        // write the 64 x T tile: PPS lanes cover one waveform's T samples
-#pragma unroll
-        for (int i = 0; i < PPS; ++i) {
-            const int s = i * SPI + lane / PPS, p = lane % PPS;
-            const uint32_t slen = tab_len[s];
-            const uint32_t tpos = t0 + 8u * (uint32_t)p;
-            if (tpos < slen) {
-                const uint32_t *src = obuf + s * OSW + 4 * p;
-                uint4 v;
-                v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
-                int16_t *dst = out + tab_ooff[s] + tpos;
-                if (tpos + 8u <= slen && ((uintptr_t)dst & 15u) == 0) {
-                    *reinterpret_cast<uint4 *>(dst) = v;
-                } else {
-                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (tpos + (uint32_t)j < slen) dst[j] = (int16_t)(w[j >> 1] >> (16 * (j & 1)));
-                }
-            }
-        }
-        wave_sync();
-    }
-}
-
-// Second-generation staged decoder.  Same decomposition as k_decode_lanes (one lane per
-// waveform, LDS ring per lane, LDS transpose of the output), restructured around latency
-// and occupancy (rocprofv3 PMC, profiles/r01_*: the first version spent 34 % of its wave
-// cycles in s_waitcnt and 55 % of its LDS cycles in bank conflicts, at 7 waves per CU):
-//   * the per-sample loop is branch free: the next stream word is prefetched from the ring
-//     one refill ahead, so neither LDS latency nor an exec-mask branch sits on the serial
-//     bit-position recurrence;
-//   * the ring is word-major, ring[slot][lane]: a lane's bank is its lane number whatever
-//     slot it reads, so the per-sample reads never conflict although the 64 streams drift;
-//   * every lane fetches its own next piece (LW words: a whole 128-byte line, or half of
-//     one) with 16-byte loads issued back to back and one wait; each byte of the stream is
-//     requested exactly once;
-//   * RW = 32 ring words (two 64-byte pieces) and T = 16..32 keep a wave at ~11-13 KB of
-//     LDS, i.e. 12-14 waves per CU instead of 7.
-template <int RW, int LW, int T>
-__global__ __launch_bounds__(64) void k_decode_lanes2(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
-                                                      const uint64_t *__restrict__ wave_off,
-                                                      const uint32_t *__restrict__ wave_words,
-                                                      int16_t *__restrict__ out) {
-    static_assert(RW >= 2 * LW && (RW & (RW - 1)) == 0 && (LW == 16 || LW == 32), "ring geometry");
-    constexpr int OSW = T / 2 + 1;  // output row stride in words (odd: conflict-free rows)
-    constexpr int PPS = T / 8;      // 16-byte pieces per stream per round
-    constexpr int SPI = 64 / PPS;   // streams per write-out iteration
-    constexpr int NV = LW / 4;      // 16-byte loads per piece
-    __shared__ uint32_t ring[RW * 64];
-    __shared__ uint32_t obuf[64 * OSW];
-    __shared__ uint64_t tab_ooff[64];
-    __shared__ uint32_t tab_len[64];
-
-    const int lane = lane_id();
-    const uint64_t g = (uint64_t)blockIdx.x * 64u + lane;
-    const bool active = g < G.total_waves;
-    const uint32_t k = G.k;
-
-    uint32_t len = 0, n = 0;
-    uint64_t S = 0, ooff = 0;
-    if (active) {
-        const WaveRef r = locate(G, g);
-        len = r.len;
-        ooff = r.sample_off;
-        S = wave_off[g] + 1u;
-        n = wave_words[g];
-    }
-    tab_ooff[lane] = ooff;
-    tab_len[lane] = len;
-    const uint64_t A = S & ~(uint64_t)(RW - 1);  // ring slot of word w = (w - A) mod RW
-    const uint32_t s0 = (uint32_t)(S - A);
-    const uint32_t endw = s0 + n;
-    uint32_t flw = s0 & ~(uint32_t)(LW - 1);  // words loaded so far (whole pieces), relative to A
-    uint32_t rdw = s0;  // index of the word held in `nxt` (after start-up); words >= rdw stay in the ring
-    const bool in_vec_ok = ((uintptr_t)in & 15u) == 0;
-    const uint32_t maxlen = wave_max_u32(len);
-    uint32_t *myring = ring + lane;  // slot i of this lane: myring[i * 64]
-    typedef uint16_t __attribute__((may_alias)) u16a;
-    u16a *myout = reinterpret_cast<u16a *>(obuf + lane * OSW);
-
-    auto top_up = [&]() {
-        for (;;) {
-            // a new piece overwrites the slots of words [flw-RW, flw-RW+LW): all must be < rdw
-            const bool need = (flw < endw) && (flw + (uint32_t)LW <= rdw + (uint32_t)RW);
-            if (__ballot(need) == 0) break;
-            if (need && !(G.dbg & 2u)) {
-                const uint64_t a = A + flw;
-                uint4 v[NV];
-                if (in_vec_ok && a + (uint32_t)LW <= in_words) {
-#pragma unroll
-                    for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const uint4 *>(in + a + 4 * j);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < NV; ++j) {
-                        v[j].x = (a + 4 * j + 0 < in_words) ? in[a + 4 * j + 0] : 0u;
-                        v[j].y = (a + 4 * j + 1 < in_words) ? in[a + 4 * j + 1] : 0u;
-                        v[j].z = (a + 4 * j + 2 < in_words) ? in[a + 4 * j + 2] : 0u;
-                        v[j].w = (a + 4 * j + 3 < in_words) ? in[a + 4 * j + 3] : 0u;
-                    }
-                }
-                uint32_t *dst = myring + (flw & (uint32_t)(RW - 1)) * 64u;
-#pragma unroll
-                for (int j = 0; j < NV; ++j) {
-                    dst[(4 * j + 0) * 64] = v[j].x; dst[(4 * j + 1) * 64] = v[j].y;
-                    dst[(4 * j + 2) * 64] = v[j].z; dst[(4 * j + 3) * 64] = v[j].w;
-                }
-            }
-            if (need) flw += (uint32_t)LW;
-            wave_sync();
-        }
-    };
-
-    wave_sync();
-    top_up();
-    // window = alignbit(hi, lo, s): the 32 stream bits that start s bits above the bottom of hi
-    uint32_t hi = 0, lo = myring[(rdw & (RW - 1)) * 64u];
-    ++rdw;
-    uint32_t nxt = myring[(rdw & (RW - 1)) * 64u];
-    int32_t s = 0;
-    int32_t acc = 0;
-    const uint32_t kp1 = k + 1u, c31k = 31u - k;
-
-    for (uint32_t t0 = 0; t0 < maxlen; t0 += T) {
-#pragma unroll 1
-        for (int tg = 0; tg < T; tg += 4) {
-            // a group of 4 samples moves the prefetch pointer by at most 4 words
-            if (__any((flw - rdw < 6u) && (flw < endw))) top_up();
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t win = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)s);
-                uint32_t q;  // leading zeros; 0xffffffff for win == 0, which is an escape anyway
-                asm("v_ffbh_u32 %0, %1" : "=v"(q) : "v"(win));
-                const bool esc = win < (1u << 24);  // 8 (or more) leading zeros
-                const uint32_t rem = __builtin_amdgcn_ubfe(win, c31k - q, k);
-                const uint32_t z_ne = (q << k) + rem;
-                const uint32_t z = esc ? __builtin_amdgcn_ubfe(win, 7u, 16u) : z_ne;
-                const uint32_t used = esc ? 25u : q + kp1;
-                acc += (int32_t)(z >> 1) ^ -(int32_t)(z & 1u);
-                myout[tg + u] = (uint16_t)acc;
-                const int32_t s2 = s - (int32_t)used;
-                const bool take = s2 < 0;
-                s = s2 & 31;
-                hi = take ? lo : hi;
-                lo = take ? nxt : lo;
-                rdw += take ? 1u : 0u;
-                nxt = myring[(rdw & (RW - 1)) * 64u];
-            }
-        }
-        wave_sync();
-#pragma unroll
-        for (int i = 0; i < PPS; ++i) {
-            const int st = i * SPI + lane / PPS, p = lane % PPS;
-            const uint32_t slen = tab_len[st];
-            const uint32_t tpos = t0 + 8u * (uint32_t)p;
-            if (tpos < slen && !(G.dbg & 1u)) {
-                const uint32_t *src = obuf + st * OSW + 4 * p;
-                uint4 v;
-                v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
-                int16_t *dst = out + tab_ooff[st] + tpos;
-                if (tpos + 8u <= slen && ((uintptr_t)dst & 15u) == 0) {
-                    *reinterpret_cast<uint4 *>(dst) = v;
-                } else {
-                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (tpos + (uint32_t)j < slen) dst[j] = (int16_t)(w[j >> 1] >> (16 * (j & 1)));
-                }
-            }
-        }
-        wave_sync();
-    }
-}
-
-// Third-generation staged decoder: minimum VALU work per sample.
+// Staged lane-per-waveform decoder (the production kernel; generations 1-4 are in the git
+// history, what each measurement changed is in DESIGN.md).
 //
-// Measured (profiles/r01_*): with loads and stores ablated k_decode_lanes2 takes the same
-// 1.4 ms per 1.4e9 samples at 7 and at 12 waves per CU -- the kernel is bound by VALU issue
-// (a wave64 VALU instruction occupies its SIMD for 4 cycles), not by latency or HBM.  So the
-// lever is instructions per sample.  Here the bit position is kept negated, Q = -P (mod 2^32),
-// and the ring is stored in reverse word order with one mirror row, so that
-//     row   = Q[5 +: log2 RW]            (v_bfe)        row of the word after the current one
-//     words = ring[row], ring[row + 1]   (ds_read2_b32) "lo" and "hi"
-//     win   = alignbit(hi, lo, Q)        (shift uses Q[4:0])
-// forms the 32-bit window in 3 VALU + 1 LDS instruction with no per-sample refill state at
-// all; escape and ordinary codes share one extraction (payload width kk = esc ? 16 : k; the
-// stray high bits an escape leaves above bit 15 never reach the int16 running sum).
-template <int RW, int LW, int T, bool ALIGNED>
-__global__ __launch_bounds__(64) void k_decode_lanes3(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
-                                                      const uint64_t *__restrict__ wave_off,
-                                                      const uint32_t *__restrict__ wave_words,
-                                                      int16_t *__restrict__ out) {
-    static_assert(RW >= 2 * LW && (RW == 32 || RW == 64 || RW == 128) && (LW == 16 || LW == 32), "ring geometry");
-    constexpr int LOG_RW = RW == 32 ? 5 : (RW == 64 ? 6 : 7);
-    constexpr int GS = 8;           // samples between two refill checks
-    constexpr int OSW = T / 2 + 1;  // output row stride in words (odd: conflict-free rows)
-    constexpr int PPS = T / 8;      // 16-byte pieces per stream per round
-    constexpr int SPI = 64 / PPS;   // streams per write-out iteration
-    constexpr int NV = LW / 4;      // 16-byte loads per piece
-    constexpr uint32_t WMASK = (1u << 27) - 1u;  // word indices derived from Q live mod 2^27
-    static_assert(T % GS == 0, "round length");
-    // ring row r (r = 0..RW) holds, for every lane, the stream word w with RW - (w mod RW) == r;
-    // row 0 mirrors row RW so that the pair (w, w+1) is always (row+1, row).
-    __shared__ uint32_t ring[(RW + 1) * 64];
-    __shared__ uint32_t obuf[64 * OSW];
-    __shared__ uint64_t tab_ooff[64];  // sample offset of step 0 of round 0 (may lie before the waveform)
-    __shared__ uint32_t tab_lo[64];    // first and one-past-last step of the stream that carry samples
-    __shared__ uint32_t tab_hi[64];
-
-    const int lane = lane_id();
-    const uint64_t g = (uint64_t)blockIdx.x * 64u + lane;
-    const bool active = g < G.total_waves;
-    const uint32_t k = G.k;
-
-    uint32_t len = 0, n = 0;
-    uint64_t S = 1, ooff = 0;
-    if (active) {
-        const WaveRef r = locate(G, g);
-        len = r.len;
-        ooff = r.sample_off;
-        S = wave_off[g] + 1u;
-        n = wave_words[g];
-    }
-    // ALIGNED: lane-private start delay phi so that step u of every round lands on a sample whose
-    // address is u*2 past a T*2-byte boundary: each round then stores whole aligned sectors
-    // (rocprofv3: unaligned 64-byte pieces made the L2 emit 1.6x the write requests).
-    const uint32_t phi = (ALIGNED && active) ? (uint32_t)((((uintptr_t)out >> 1) + ooff) & (uint64_t)(T - 1)) : 0u;
-    tab_ooff[lane] = ooff - phi;
-    tab_lo[lane] = phi;
-    tab_hi[lane] = phi + len;
-    // word indices are relative to A, one whole ring below the stream start, so s0 is in [RW, 2 RW)
-    const uint64_t A = (S & ~(uint64_t)(RW - 1)) - (uint64_t)RW;
-    const uint32_t s0 = (uint32_t)(S - A);
-    const uint32_t endw = s0 + n;
-    uint32_t flw = s0 & ~(uint32_t)(LW - 1);  // words loaded so far (whole pieces)
-    const bool in_vec_ok = ((uintptr_t)in & 15u) == 0;
-    const uint32_t maxlen = wave_max_u32(len + phi);
-    uint32_t *myring = ring + lane;
-    typedef uint16_t __attribute__((may_alias)) u16a;
-    u16a *myout = reinterpret_cast<u16a *>(obuf + lane * OSW);
-
-    // loads the piece [flw, flw + LW) of this lane's stream into its ring rows
-    auto load_piece = [&](bool need) {
-        if (need && !(G.dbg & 2u)) {
-            const uint64_t a = A + flw;
-            uint4 v[NV];
-            if (in_vec_ok && a + (uint32_t)LW <= in_words) {
-#pragma unroll
-                for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const uint4 *>(in + a + 4 * j);
-            } else {
-#pragma unroll
-                for (int j = 0; j < NV; ++j) {
-                    v[j].x = (a + 4 * j + 0 < in_words) ? in[a + 4 * j + 0] : 0u;
-                    v[j].y = (a + 4 * j + 1 < in_words) ? in[a + 4 * j + 1] : 0u;
-                    v[j].z = (a + 4 * j + 2 < in_words) ? in[a + 4 * j + 2] : 0u;
-                    v[j].w = (a + 4 * j + 3 < in_words) ? in[a + 4 * j + 3] : 0u;
-                }
-            }
-            const uint32_t r0 = (uint32_t)RW - (flw & (uint32_t)(RW - 1));  // row of the piece's first word
-            uint32_t *dst = myring + r0 * 64u;                              // following words: rows r0-1, r0-2, ...
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                dst[-(4 * j + 0) * 64] = v[j].x; dst[-(4 * j + 1) * 64] = v[j].y;
-                dst[-(4 * j + 2) * 64] = v[j].z; dst[-(4 * j + 3) * 64] = v[j].w;
-            }
-            if (r0 == (uint32_t)RW) myring[0] = v[0].x;  // mirror row
-        }
-        if (need) flw += (uint32_t)LW;
-    };
-
-    uint32_t Q = 0u - 32u * s0;  // minus the bit position (relative to A)
-
-    auto top_up = [&]() {
-        for (;;) {
-            const uint32_t cw = (~Q) >> 5;  // word that holds the bit before the current one; words >= cw are live
-            const uint32_t avail = (flw - cw) & WMASK;
-            // the new piece overwrites the rows of words [flw-RW, flw-RW+LW): all must be < cw
-            const bool need = (flw < endw) && (avail <= (uint32_t)(RW - LW));
-            if (__ballot(need) == 0) break;
-            load_piece(need);
-            wave_sync();
-        }
-    };
-
-    wave_sync();
-    load_piece(flw < endw);  // start-up: the piece that holds word s0 and the one after it
-    load_piece(flw < endw);
-    wave_sync();
-    int32_t acc = 0;
-
-    auto run_round = [&](auto first_tag) {
-        constexpr bool FIRST = decltype(first_tag)::value;  // round 0: steps < phi are idle for this lane
-#pragma unroll 1
-        for (int tg = 0; tg < T; tg += GS) {
-            {   // GS samples touch words up to cw + GS + 1
-                const uint32_t cw = (~Q) >> 5;
-                if (__any((((flw - cw) & WMASK) < (uint32_t)(GS + 2)) && (flw < endw))) top_up();
-            }
-#pragma unroll
-            for (int u = 0; u < GS; ++u) {
-                const uint32_t row = __builtin_amdgcn_ubfe(Q, 5u, (uint32_t)LOG_RW);
-                const uint32_t *wp = myring + row * 64u;
-                const uint32_t lo = wp[0], hi = wp[64];
-                const uint32_t win = __builtin_amdgcn_alignbit(hi, lo, Q);
-                // leading zeros; win == 0 only occurs past the end of a (corrupt) stream, where any value will do
-                const uint32_t q = (uint32_t)__builtin_clz(win);
-                const bool esc = win < (1u << 24);
-                const uint32_t kk = esc ? 16u : k;
-                const uint32_t used = q + kk + 1u;
-                const uint32_t rem = __builtin_amdgcn_ubfe(win, 32u - used, kk);
-                const uint32_t z = (q << kk) + rem;  // escape: 8 << 16 stays above bit 15
-                const int32_t d = (int32_t)(z >> 1) ^ -(int32_t)(z & 1u);
-                if (FIRST && ALIGNED) {
-                    const bool act = (uint32_t)(tg + u) >= phi;
-                    acc = act ? acc + d : acc;
-                    Q = act ? Q - used : Q;
-                } else {
-                    acc += d;
-                    Q -= used;
-                }
-                myout[tg + u] = (uint16_t)acc;
-            }
-        }
-    };
-
-    for (uint32_t t0 = 0; t0 < maxlen; t0 += T) {
-        if (ALIGNED && t0 == 0) run_round(std::true_type{});
-        else run_round(std::false_type{});
-        wave_sync();
-#pragma unroll
-        for (int i = 0; i < PPS; ++i) {
-            const int st = i * SPI + lane / PPS, p = lane % PPS;
-            const uint32_t slo = tab_lo[st], shi = tab_hi[st];
-            const uint32_t tpos = t0 + 8u * (uint32_t)p;  // step index of the piece's first sample
-            if (tpos + 8u > slo && tpos < shi && !(G.dbg & 1u)) {
-                const uint32_t *src = obuf + st * OSW + 4 * p;
-                uint4 v;
-                v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
-                int16_t *dst = out + tab_ooff[st] + tpos;
-                if (tpos >= slo && tpos + 8u <= shi && ((uintptr_t)dst & 15u) == 0) {
-                    *reinterpret_cast<uint4 *>(dst) = v;
-                } else {
-                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (tpos + (uint32_t)j >= slo && tpos + (uint32_t)j < shi)
-                            dst[j] = (int16_t)(w[j >> 1] >> (16 * (j & 1)));
-                }
-            }
-        }
-        wave_sync();
-    }
-}
-
-// Fourth generation: k_decode_lanes3's per-sample core with the per-round overheads
-// trimmed (PMC: the core is 14.5 VALU per sample and VALU issue, 4 cycles per wave64
-// instruction, is the binding resource, so everything around the core is pure loss):
-//   * stream pieces are prefetched: the loads of a piece are issued as soon as most lanes
-//     have room for it and are written to the ring only when a lane is about to need
-//     them, so the ~2 us HBM round trip overlaps ~100 samples of decoding instead of
-//     stalling the wave 60-odd times per waveform;
-//   * the write-out of interior rounds (every stream fully inside its waveform -- all but
-//     the first and last round or two) is one ds_read_b128 + one 16-byte store per piece,
-//     with the piece addresses held in registers;
-//   * refill checks every 16 samples instead of every 8.
-template <int RW, int LW, int T>
-__global__ __launch_bounds__(64) void k_decode_lanes4(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
-                                                      const uint64_t *__restrict__ wave_off,
-                                                      const uint32_t *__restrict__ wave_words,
-                                                      int16_t *__restrict__ out) {
-    static_assert(RW >= 2 * LW && (RW == 32 || RW == 64 || RW == 128) && (LW == 16 || LW == 32), "ring geometry");
-    constexpr int LOG_RW = RW == 32 ? 5 : (RW == 64 ? 6 : 7);
-    constexpr int GS = 16;          // samples between two refill checks
-    constexpr int OSW = T / 2 + 4;  // output row stride in words (16-byte aligned rows)
-    constexpr int PPS = T / 8;      // 16-byte pieces per stream per round
-    constexpr int SPI = 64 / PPS;   // streams per write-out iteration
-    constexpr int NV = LW / 4;      // 16-byte loads per piece
-    constexpr uint32_t WMASK = (1u << 27) - 1u;
-    constexpr uint32_t ISSUE_AT = RW - LW - 8;  // prefetch once some lane is this far into its free space
-    static_assert(T % GS == 0 && RW - LW >= GS + 2, "round length / ring slack");
-    __shared__ uint32_t ring[(RW + 1) * 64];  // row r: word w with RW - (w mod RW) == r; row 0 mirrors row RW
-    __shared__ __attribute__((aligned(16))) uint32_t obuf[64 * OSW];
-    __shared__ uint64_t tab_base[64];  // byte address of step 0 of round 0 of each stream
-    __shared__ uint32_t tab_lo[64], tab_hi[64];
-
-    const int lane = lane_id();
-    const uint64_t g = (uint64_t)blockIdx.x * 64u + lane;
-    const bool active = g < G.total_waves;
-    const uint32_t k = G.k;
-
-    uint32_t len = 0, n = 0;
-    uint64_t S = 1, ooff = 0;
-    if (active) {
-        const WaveRef r = locate(G, g);
-        len = r.len;
-        ooff = r.sample_off;
-        S = wave_off[g] + 1u;
-        n = wave_words[g];
-    }
-    // start delay: step u of every round sits u*2 bytes past a T*2-byte boundary (see k_decode_lanes3)
-    const uint32_t phi = active ? (uint32_t)((((uintptr_t)out >> 1) + ooff) & (uint64_t)(T - 1)) : 0u;
-    tab_base[lane] = (uint64_t)(uintptr_t)out + 2u * (ooff - phi);
-    tab_lo[lane] = phi;
-    tab_hi[lane] = phi + len;
-    const uint32_t steps = wave_max_u32(len + phi);
-    const uint32_t lo_max = wave_max_u32(phi);
-    const uint32_t hi_min = ~wave_max_u32(~(phi + len));
-
-    const uint64_t A = (S & ~(uint64_t)(RW - 1)) - (uint64_t)RW;  // s0 in [RW, 2 RW)
-    const uint32_t s0 = (uint32_t)(S - A);
-    const uint32_t endw = s0 + n;
-    uint32_t flw = s0 & ~(uint32_t)(LW - 1);
-    const bool in_vec_ok = ((uintptr_t)in & 15u) == 0;
-    uint32_t *myring = ring + lane;
-    typedef uint16_t __attribute__((may_alias)) u16a;
-    u16a *myout = reinterpret_cast<u16a *>(obuf + lane * OSW);
-    wave_sync();
-
-    // write-out constants of this lane: piece p of stream st_i, i = 0..PPS-1
-    uint64_t wo_addr[PPS];
-    uint32_t wo_lo[PPS], wo_hi[PPS];
-#pragma unroll
-    for (int i = 0; i < PPS; ++i) {
-        const int st = i * SPI + lane / PPS, p = lane % PPS;
-        wo_addr[i] = tab_base[st] + 16u * (uint32_t)p;
-        wo_lo[i] = tab_lo[st];
-        wo_hi[i] = tab_hi[st];
-    }
-
-    uint4 pv[NV];        // piece in flight
-    bool pneed = false;  // this lane has a piece in flight
-    bool pend = false;   // some lane has (wave uniform)
-
-    auto issue = [&](bool need) {
-        pneed = need;
-        if (need && !(G.dbg & 2u)) {
-            const uint64_t a = A + flw;
-            if (in_vec_ok && a + (uint32_t)LW <= in_words) {
-#pragma unroll
-                for (int j = 0; j < NV; ++j) pv[j] = *reinterpret_cast<const uint4 *>(in + a + 4 * j);
-            } else {
-#pragma unroll
-                for (int j = 0; j < NV; ++j) {
-                    pv[j].x = (a + 4 * j + 0 < in_words) ? in[a + 4 * j + 0] : 0u;
-                    pv[j].y = (a + 4 * j + 1 < in_words) ? in[a + 4 * j + 1] : 0u;
-                    pv[j].z = (a + 4 * j + 2 < in_words) ? in[a + 4 * j + 2] : 0u;
-                    pv[j].w = (a + 4 * j + 3 < in_words) ? in[a + 4 * j + 3] : 0u;
-                }
-            }
-        }
-    };
-    auto commit = [&]() {
-        if (pneed) {
-            if (!(G.dbg & 2u)) {
-                const uint32_t r0 = (uint32_t)RW - (flw & (uint32_t)(RW - 1));
-                uint32_t *dst = myring + r0 * 64u;
-#pragma unroll
-                for (int j = 0; j < NV; ++j) {
-                    dst[-(4 * j + 0) * 64] = pv[j].x; dst[-(4 * j + 1) * 64] = pv[j].y;
-                    dst[-(4 * j + 2) * 64] = pv[j].z; dst[-(4 * j + 3) * 64] = pv[j].w;
-                }
-                if (r0 == (uint32_t)RW) myring[0] = pv[0].x;
-            }
-            flw += (uint32_t)LW;
-        }
-        pneed = false;
-        wave_sync();
-    };
-
-    uint32_t Q = 0u - 32u * s0;  // minus the bit position (relative to A)
-    issue(flw < endw); commit();  // start-up: the piece holding word s0 and the one after it
-    issue(flw < endw); commit();
-    int32_t acc = 0;
-
-    // refill policy, run every GS samples (GS samples touch words up to cw + GS + 1)
-    auto refill = [&]() {
-        uint32_t avail = (flw - ((~Q) >> 5)) & WMASK;
-        if (pend && __any((flw < endw) && avail < (uint32_t)(GS + 2))) { commit(); pend = false; }
-        if (!pend) {
-            for (;;) {  // lanes that were not part of the last piece may be dry: serve them synchronously
-                avail = (flw - ((~Q) >> 5)) & WMASK;
-                if (!__any((flw < endw) && avail < (uint32_t)(GS + 2))) break;
-                issue((flw < endw) && avail <= (uint32_t)(RW - LW));
-                commit();
-            }
-            if (__any((flw < endw) && avail <= ISSUE_AT)) {
-                issue((flw < endw) && avail <= (uint32_t)(RW - LW));
-                pend = true;
-            }
-        }
-    };
-
-    auto run_round = [&](auto first_tag) {
-        constexpr bool FIRST = decltype(first_tag)::value;  // round 0: steps < phi are idle for this lane
-#pragma unroll 1
-        for (int tg = 0; tg < T; tg += GS) {
-            refill();
-#pragma unroll
-            for (int u = 0; u < GS; ++u) {
-                const uint32_t row = __builtin_amdgcn_ubfe(Q, 5u, (uint32_t)LOG_RW);
-                const uint32_t *wp = myring + row * 64u;
-                const uint32_t lo = wp[0], hi = wp[64];
-                const uint32_t win = __builtin_amdgcn_alignbit(hi, lo, Q);
-                const uint32_t q = (uint32_t)__builtin_clz(win);  // win == 0 only past the end of a corrupt stream
-                const bool esc = win < (1u << 24);
-                const uint32_t kk = esc ? 16u : k;
-                const uint32_t used = q + kk + 1u;
-                const uint32_t rem = __builtin_amdgcn_ubfe(win, 32u - used, kk);
-                const uint32_t z = (q << kk) + rem;  // escape: 8 << 16 stays above bit 15
-                const int32_t d = (int32_t)(z >> 1) ^ -(int32_t)(z & 1u);
-                if (FIRST) {
-                    const bool act = (uint32_t)(tg + u) >= phi;
-                    acc = act ? acc + d : acc;
-                    Q = act ? Q - used : Q;
-                } else {
-                    acc += d;
-                    Q -= used;
-                }
-                myout[tg + u] = (uint16_t)acc;
-            }
-        }
-    };
-
-    for (uint32_t t0 = 0; t0 < steps; t0 += T) {
-        if (t0 == 0) run_round(std::true_type{});
-        else run_round(std::false_type{});
-        wave_sync();
-        if (!(G.dbg & 1u)) {
-            if (t0 >= lo_max && t0 + T <= hi_min) {  // interior round: whole aligned pieces only
-#pragma unroll
-                for (int i = 0; i < PPS; ++i) {
-                    const int st = i * SPI + lane / PPS, p = lane % PPS;
-                    const uint4 v = *reinterpret_cast<const uint4 *>(obuf + st * OSW + 4 * p);
-                    uint4 *dst4 = reinterpret_cast<uint4 *>(wo_addr[i] + 2u * (uint64_t)t0);
-                    if (G.dbg & 4u) {
-                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                        u32x4 nv = {v.x, v.y, v.z, v.w};
-                        __builtin_nontemporal_store(nv, reinterpret_cast<u32x4 *>(dst4));
-                    } else {
-                        *dst4 = v;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < PPS; ++i) {
-                    const int st = i * SPI + lane / PPS, p = lane % PPS;
-                    const uint32_t tpos = t0 + 8u * (uint32_t)p;  // step index of the piece's first sample
-                    if (tpos + 8u > wo_lo[i] && tpos < wo_hi[i]) {
-                        const uint4 v = *reinterpret_cast<const uint4 *>(obuf + st * OSW + 4 * p);
-                        int16_t *dst = reinterpret_cast<int16_t *>(wo_addr[i] + 2u * (uint64_t)t0);
-                        if (tpos >= wo_lo[i] && tpos + 8u <= wo_hi[i]) {
-                            *reinterpret_cast<uint4 *>(dst) = v;
-                        } else {
-                            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                            for (int j = 0; j < 8; ++j)
-                                if (tpos + (uint32_t)j >= wo_lo[i] && tpos + (uint32_t)j < wo_hi[i])
-                                    dst[j] = (int16_t)(w[j >> 1] >> (16 * (j & 1)));
-                        }
-                    }
-                }
-            }
-        }
-        wave_sync();
-    }
-}
-
-// Fifth generation = k_decode_lanes4 reshaped by what the store micro-benchmark showed
-// (tools/ubench_store.hip, profiles/r01_ubench_store.txt): 16-byte stores reach 5.5 TB/s
-// only when every contiguous run is a whole 128-byte line; 64-byte aligned runs give
-// 4.2 TB/s and runs that straddle lines 2.6-3.3 TB/s whatever their length.  So T = 64:
-// every round ends with one aligned 128-byte line per waveform.  Also fixed here: stores
-// are global_ (not flat_) instructions, the prefetched piece never crosses a duplicated
-// loop body (the start-up round refills synchronously), the in-flight piece is committed
-// before the round's stores are issued (vmcnt is in order: a load issued after a store
-// cannot be waited for without waiting for the store), and the refill test is one
-// compare against a per-lane limit position.
-template <int RW, int LW, int T, int GS>
-__global__ __launch_bounds__(64) void k_decode_lanes5(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
-                                                      const uint64_t *__restrict__ wave_off,
-                                                      const uint32_t *__restrict__ wave_words,
-                                                      int16_t *__restrict__ out) {
+// Decomposition.  The Rice parse is serial inside a waveform, so the unit of parallelism is the
+// waveform: one lane per waveform, 64 waveforms per wavefront.
+//   stream in   each lane owns an LDS ring of RW words of its compressed stream, refilled in
+//               pieces of LW words by 16-byte loads (every byte of the stream is requested once;
+//               rocprofv3: TCC_EA0_RDREQ x 128 B = the stream size).  A piece is loaded ahead of
+//               need and written to the ring just before the round's stores are issued (vmcnt is
+//               in order: a load issued after a store cannot be waited for without that store).
+//   ring layout word-major and reversed, ring[RW - (w mod RW)][lane], plus a mirror row: a lane's
+//               bank is its lane number whatever row it reads (no conflicts although the 64
+//               streams drift apart), and the pair (w, w+1) is always (row+1, row).
+//   per sample  the bit position is kept negated, Q = -P: row = Q[5 +: log2 RW] (v_bfe),
+//               (lo, hi) = ds_read2st64_b32, win = v_alignbit(hi, lo, Q): 3 VALU + 1 LDS
+//               instruction form the 32-bit window, no refill state.  Escape and ordinary codes
+//               share one extraction (payload width kk = esc ? 16 : k; the 8 << 16 an escape leaves
+//               above bit 15 never reaches the int16 running sum).  14.5 VALU instructions per
+//               sample; the kernel is bound by VALU issue (4 cycles per wave64 instruction).
+//   samples out transposed through LDS; a lane-private start delay phi makes step u of every round
+//               land u*2 bytes past a T*2-byte boundary, so each round stores whole aligned
+//               128-byte lines (T = 64).  tools/ubench_store.hip: 16-byte stores reach 5.5 TB/s only
+//               when every contiguous run is a whole line; 64-byte aligned runs give 4.2 TB/s and
+//               runs that straddle lines 2.6-3.3 TB/s whatever their length.
+//   FUSED       the header-chain walk runs inside the same launch: workgroups take a ticket; the first
+//               ceil(n_chunks/64) tickets walk (one lane per chunk, publishing one granule per
+//               waveform), every later ticket decodes 64 waveforms of one chunk as soon as their
+//               granules appear.  Decode tickets are dealt group-major (waveforms 0-63 of every chunk,
+//               then 64-127 of every chunk, ...), the order in which the 2000-hop chains release them,
+//               so the ~1.7 ms of dependent-load latency of the walk disappears behind the decode.
+//               A ticket holder is by construction running, so waiting on a lower ticket's walker
+//               cannot deadlock whatever the dispatch order.  (Uniform batches only.)
+template <int RW, int LW, int T, int GS, bool FUSED>
+__global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
+                                                     const uint64_t *__restrict__ chunk_word_off,
+                                                     uint64_t *__restrict__ wave_off,
+                                                     uint32_t *__restrict__ wave_words,
+                                                     uint64_t *__restrict__ granules, uint32_t *__restrict__ ticket,
+                                                     DevStatus *st, int16_t *__restrict__ out) {
     static_assert(RW >= 2 * LW && (RW == 32 || RW == 64 || RW == 128) && (LW == 8 || LW == 16 || LW == 32), "ring");
     constexpr int LOG_RW = RW == 32 ? 5 : (RW == 64 ? 6 : 7);
     constexpr int OSW = T / 2 + 4;  // output row stride in words (16-byte aligned rows)
@@ -1422,18 +781,57 @@ __global__ __launch_bounds__(64) void k_decode_lanes5(Geom G, const uint32_t *__
     static_assert(64 * OSW >= 256, "tables fit in obuf");
 
     const int lane = lane_id();
-    const uint64_t g = (uint64_t)blockIdx.x * 64u + lane;
-    const bool active = g < G.total_waves;
     const uint32_t k = G.k;
-
+    uint64_t g;
+    bool active;
     uint32_t len = 0, n = 0;
     uint64_t S = 1, ooff = 0;
-    if (active) {
-        const WaveRef r = locate(G, g);
-        len = r.len;
-        ooff = r.sample_off;
-        S = wave_off[g] + 1u;
-        n = wave_words[g];
+    if (FUSED) {
+        uint32_t tk = 0;
+        if (lane == 0) tk = atomicAdd(ticket, 1u);
+        tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+        const uint32_t n_walk = (uint32_t)((G.n_chunks + 63u) >> 6);
+        if (tk < n_walk) {  // walker role
+            const uint64_t c = (uint64_t)tk * 64u + lane;
+            if (c < G.n_chunks) walk_chunk(G, c, in, in_words, chunk_word_off, wave_off, wave_words, granules, st);
+            return;
+        }
+        const uint64_t t2 = tk - n_walk;                 // decode ticket, group-major
+        const uint64_t grp = t2 / G.n_chunks, c = t2 - grp * G.n_chunks;
+        const uint32_t idx = (uint32_t)grp * 64u + lane;  // waveform index inside chunk c
+        active = idx < G.u_n_waves;
+        g = c * G.u_n_waves + idx;
+        uint64_t gr = 0;
+        if (active) {
+            len = (idx + 1 == G.u_n_waves) ? (G.u_n_samples - idx * G.u_wave_len) : G.u_wave_len;
+            ooff = c * (uint64_t)G.u_n_samples + (uint64_t)idx * G.u_wave_len;
+        }
+        uint32_t spins = 0;
+        for (;;) {  // wait for this wave's granules; the walker that writes them holds a lower ticket
+            if (active && !(gr & kGranValid))
+                gr = __hip_atomic_load(granules + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!__any(active && !(gr & kGranValid))) break;
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1u << 24)) {  // cannot happen; never hang the GPU
+                if (lane == 0) atomicOr(&st->err, kErrInternal);
+                gr |= kGranValid;
+                break;
+            }
+        }
+        if (active) {
+            n = (uint32_t)(gr >> 32) & 0x7fffffffu;
+            S = chunk_word_off[c] + (uint32_t)gr + 1u;
+        }
+    } else {
+        g = (uint64_t)blockIdx.x * 64u + lane;
+        active = g < G.total_waves;
+        if (active) {
+            const WaveRef r = locate(G, g);
+            len = r.len;
+            ooff = r.sample_off;
+            S = wave_off[g] + 1u;
+            n = wave_words[g];
+        }
     }
     // start delay: step u of every round sits u*2 bytes past a T*2-byte boundary
     const uint32_t phi = active ? (uint32_t)((((uintptr_t)out >> 1) + ooff) & (uint64_t)(T - 1)) : 0u;
@@ -1686,38 +1084,35 @@ hipError_t launch_encode(const Geom &G, const int16_t *d_in, uint32_t *d_out, ui
 
 hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                          const uint64_t *d_chunk_word_off, int16_t *d_out, uint64_t *d_wave_off,
-                         uint32_t *d_wave_words, DevStatus *d_status, int impl, hipEvent_t *ev, hipStream_t s) {
+                         uint32_t *d_wave_words, uint64_t *d_granules, DevStatus *d_status, int impl,
+                         hipEvent_t *ev, hipStream_t s) {
     if (G.total_waves == 0) return hipSuccess;
     mark(ev, 0, s);
-    k_walk<<<blocks_for(G.n_chunks, 64), 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off,
-                                                     d_wave_words, d_status);
-    mark(ev, 1, s);
-    const unsigned nb = blocks_for(G.total_waves, 64);
-    switch (impl) {
-        case 0: k_decode_simple<<<nb, 64, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_out); break;
-        case 2: k_decode_lanes<64, 32><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
-        case 3: k_decode_lanes<128, 64><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
-        case 4: k_decode_lanes2<64, 32, 32><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
-        case 5: k_decode_lanes2<32, 16, 32><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
-        case 6: k_decode_lanes2<32, 16, 16><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
-        case 7: k_decode_lanes2<64, 16, 16><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
-        case 8: k_decode_lanes2<32, 16, 64><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
-        case 9: k_decode_lanes3<32, 16, 32, false><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
-        case 10: k_decode_lanes3<64, 32, 32, false><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
-        case 11: k_decode_lanes3<64, 32, 32, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
-        case 12: k_decode_lanes3<64, 32, 64, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
-        case 13: k_decode_lanes3<32, 16, 32, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
-        case 14: k_decode_lanes3<32, 16, 64, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
-        case 15: k_decode_lanes4<64, 32, 32><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
-        case 16: k_decode_lanes4<64, 16, 32><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
-        case 17: k_decode_lanes4<64, 32, 64><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
-        case 18: k_decode_lanes4<64, 16, 64><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
-        case 19: k_decode_lanes5<32, 8, 64, 8><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
-        case 20: k_decode_lanes5<32, 16, 64, 8><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
-        case 21: k_decode_lanes5<64, 16, 64, 16><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
-        case 22: k_decode_lanes5<64, 32, 64, 16><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
-        case 23: k_decode_lanes5<32, 8, 32, 8><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
-        default: k_decode_lanes<64, 64><<<nb, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, d_out); break;
+    const bool fused = impl >= 5 && G.uniform;  // the in-launch walk needs the arithmetic chunk mapping
+    if (fused) {
+        // granules + ticket word, zeroed before every launch (a granule is its own ready flag)
+        hipError_t e = hipMemsetAsync(d_granules, 0, (G.total_waves + 2) * sizeof(uint64_t), s);
+        if (e != hipSuccess) return e;
+        mark(ev, 1, s);
+        uint32_t *ticket = reinterpret_cast<uint32_t *>(d_granules + G.total_waves);
+        const unsigned n_walk = blocks_for(G.n_chunks, 64);
+        const unsigned nb = n_walk + (unsigned)(G.n_chunks * ((G.u_n_waves + 63u) / 64u));
+        switch (impl) {
+            case 6: k_decode_lanes<32, 16, 64, 8, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
+            default: k_decode_lanes<64, 16, 64, 16, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
+        }
+    } else {
+        k_walk<<<blocks_for(G.n_chunks, 64), 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off,
+                                                         d_wave_words, d_status);
+        mark(ev, 1, s);
+        const unsigned nb = blocks_for(G.total_waves, 64);
+        switch (impl) {
+            case 0: k_decode_simple<<<nb, 64, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_out); break;
+            case 2: k_decode_lanes<32, 16, 64, 8, false><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
+            case 3: k_decode_lanes<32, 8, 64, 8, false><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
+            case 4: k_decode_lanes<64, 32, 64, 16, false><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
+            default: k_decode_lanes<64, 16, 64, 16, false><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
+        }
     }
     mark(ev, 2, s);
     mark(ev, 3, s);

@@ -1,0 +1,73 @@
+"""CPU: the multi-GPU batch splitter (deltarice_amd/dist.py) on gloo, world_size 2 and 3.
+
+Each rank encodes its shard of the chunk list with the oracle (the CPU stands in for the
+rank's GPU); the one collective -- the all-gather of encoded sizes -- gives every rank the
+global offset of its part; the rank-order concatenation must be byte-identical to encoding
+the whole batch at once."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from deltarice_amd import dist as drdist
+
+
+def test_shard_range_covers_everything():
+    for n in (0, 1, 7, 500, 501, 4096):
+        for world in (1, 2, 3, 8):
+            tab = drdist.shard_table(n, world)
+            assert tab[0][0] == 0 and sum(c for _, c in tab) == n
+            for (a, ca), (b, _) in zip(tab, tab[1:]):
+                assert a + ca == b
+            assert max(c for _, c in tab) - min(c for _, c in tab) <= 1
+    with pytest.raises(ValueError):
+        drdist.shard_range(10, 0, 0)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_chunks, chunk_samples, opts, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        x = np.random.default_rng(99).normal(0, 10, n_chunks * chunk_samples).astype(np.int16)  # same on every rank
+        first, count = drdist.shard_range(n_chunks, world, rank)
+        mine = x[first * chunk_samples:(first + count) * chunk_samples]
+        if count:
+            words, off = O.encode_batch(mine, chunk_samples, opts)
+        else:
+            words, off = np.zeros(0, np.uint32), np.zeros(1, np.uint64)
+        local_off = torch.from_numpy(off.astype(np.int64))
+        goff, sizes = drdist.global_chunk_offsets(local_off)
+        assert sizes.tolist()[rank] == words.size
+        np.savez(os.path.join(outdir, f"r{rank}.npz"), words=words, goff=goff.numpy(), first=first, count=count)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_chunks", [(2, 6), (3, 7), (2, 1)])
+def test_sharded_encode_is_byte_identical(tmp_path, world, n_chunks):
+    from oracle import oracle as O
+    chunk_samples, opts = 4 * 1000, (8, 1000)
+    mp.spawn(_worker, args=(world, _free_port(), n_chunks, chunk_samples, opts, str(tmp_path)), nprocs=world, join=True)
+    x = np.random.default_rng(99).normal(0, 10, n_chunks * chunk_samples).astype(np.int16)
+    ref_words, ref_off = O.encode_batch(x, chunk_samples, opts)
+    parts = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    cat = np.concatenate([p["words"] for p in parts])
+    assert np.array_equal(cat, ref_words), "rank-order concatenation differs from the single-rank stream"
+    for p in parts:
+        f, c = int(p["first"]), int(p["count"])
+        assert np.array_equal(p["goff"], ref_off[f:f + c + 1].astype(np.int64)), "global chunk offsets differ"

@@ -1,0 +1,100 @@
+"""GPU: filter 32025 through the real HDF5 library (C API, HDF5 1.10.6 of this image) with the
+plugin loaded dynamically from HDF5_PLUGIN_PATH -- the path on which the reference's own shim
+crashes (src/deltaRice_h5plugin.c:5 returns 32025 instead of the class record).
+
+Counterpart of the reference's tests/test.py (write -> close -> reopen -> read -> equal) and of
+README.md:64-92 (BASELINE config #1), plus byte-level checks the reference never had:
+the chunks stored in the file are the oracle's / the reference's bytes, and a file holding
+chunks encoded by the CPU filter reads back through the GPU filter."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HDF5_DIR = os.environ.get("HDF5_DIR", "/opt/conda")
+
+
+@pytest.fixture(scope="module")
+def h5tool(tmp_path_factory):
+    if not os.path.exists(os.path.join(HDF5_DIR, "include", "hdf5.h")):
+        pytest.skip("no HDF5 C library in this image")
+    d = tmp_path_factory.mktemp("h5tool")
+    exe = str(d / "h5_roundtrip")
+    subprocess.run(["gcc", "-O1", "-o", exe, os.path.join(ROOT, "tests", "h5_roundtrip.c"),
+                    f"-I{HDF5_DIR}/include", f"-L{HDF5_DIR}/lib", "-lhdf5", f"-Wl,-rpath,{HDF5_DIR}/lib"], check=True)
+    env = dict(os.environ, HDF5_PLUGIN_PATH=os.path.join(ROOT, "deltarice_amd", "plugin"))
+
+    def run(*args):
+        return subprocess.run([exe, *map(str, args)], env=env, check=True, capture_output=True, text=True)
+    return run
+
+
+CASES = [
+    # rows, cols, chunk_rows, M, L, data
+    (100, 7000, 20, 8, 7000, "gauss"),      # README.md:75-82 = BASELINE config #1
+    (64, 1024, 16, 8, 1024, "uniform"),      # tests/test.py:33-44 shape
+    (32, 2048, 8, 16, 2048, "gauss"),
+    (16, 4096, 16, 8, 512, "arange"),        # several waveforms per row
+]
+
+
+@pytest.mark.parametrize("rows,cols,crows,M,L,kind", CASES)
+def test_hdf5_roundtrip_and_stored_bytes(h5tool, tmp_path, rows, cols, crows, M, L, kind):
+    from oracle import oracle as O
+    rng = np.random.default_rng(rows * cols)
+    if kind == "gauss":
+        x = rng.normal(0, 10, (rows, cols)).astype(np.int16)
+    elif kind == "uniform":
+        x = rng.integers(-32768, 32768, (rows, cols)).astype(np.int16)
+    else:
+        x = np.arange(rows * cols, dtype=np.int64).astype(np.uint16).view(np.int16).reshape(rows, cols)
+    raw, h5, back = tmp_path / "raw.bin", tmp_path / "t.h5", tmp_path / "back.bin"
+    x.tofile(raw)
+    h5tool("write", h5, raw, rows, cols, crows, M, L)           # encode on the GPU, chunk by chunk
+    h5tool("read", h5, back)                                     # decode on the GPU
+    assert np.array_equal(np.fromfile(back, np.int16).reshape(rows, cols), x)
+    # the bytes HDF5 stored are exactly the CPU filter's
+    n = int(h5tool("chunks", h5, tmp_path / "chunk").stdout)
+    assert n == rows // crows
+    for c in range(n):
+        stored = np.fromfile(f"{tmp_path}/chunk.{c}", np.uint32)
+        ref = O.encode_chunk(x[c * crows:(c + 1) * crows], (M, L))
+        assert np.array_equal(stored, ref), f"chunk {c} differs from the oracle"
+    # a file whose chunks were encoded on the CPU reads back through the GPU filter
+    for c in range(n):
+        O.encode_chunk(x[c * crows:(c + 1) * crows], (M, L)).tofile(f"{tmp_path}/cpu.{c}")
+    h5cpu, back2 = tmp_path / "cpu.h5", tmp_path / "back2.bin"
+    h5tool("writeraw", h5cpu, rows, cols, crows, M, L, tmp_path / "cpu")
+    h5tool("read", h5cpu, back2)
+    assert np.array_equal(np.fromfile(back2, np.int16).reshape(rows, cols), x)
+
+
+def test_h5dump_sees_the_filter(h5tool, tmp_path):
+    h5dump = os.path.join(HDF5_DIR, "bin", "h5dump")
+    if not os.path.exists(h5dump):
+        pytest.skip("no h5dump")
+    x = np.random.default_rng(0).normal(0, 10, (40, 7000)).astype(np.int16)
+    raw, h5 = tmp_path / "raw.bin", tmp_path / "t.h5"
+    x.tofile(raw)
+    h5tool("write", h5, raw, 40, 7000, 20, 8, 7000)
+    env = dict(os.environ, HDF5_PLUGIN_PATH=os.path.join(ROOT, "deltarice_amd", "plugin"))
+    out = subprocess.run([h5dump, "-pH", str(h5)], env=env, capture_output=True, text=True, check=True).stdout
+    assert "FILTER_ID 32025" in out and "PARAMS { 8 7000 }" in out
+
+
+def test_explicit_registration_through_python_module(tmp_path):
+    # counterpart of `import deltaRice.h5` (src/h5.pyx:55-61): explicit H5Zregister in a given libhdf5
+    import ctypes as C
+    lib = os.path.join(HDF5_DIR, "lib", "libhdf5.so")
+    if not os.path.exists(lib):
+        pytest.skip("no libhdf5")
+    h5 = C.CDLL(lib, mode=C.RTLD_GLOBAL)
+    from deltarice_amd import h5 as drh5
+    drh5.register_h5_filter(lib)
+    h5.H5Zfilter_avail.argtypes = [C.c_int]
+    assert h5.H5Zfilter_avail(32025) > 0

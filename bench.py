@@ -192,6 +192,16 @@ def main():
     achieved = algo_bytes / (dec_kernel_ms * 1e-3) / 1e9
     pack_ms = float(np.mean(np.array(coll["enc"])[:, 2]))
 
+    traffic = traffic_enc = None
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tpath) and n_waves == 1_000_000 and L == 7000 and a.m == 8 and a.dist == "gauss":
+        # HBM bytes per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE x 2 + WRITE_SIZE,
+        # see profiles/make_traffic_json.py); PMC cannot be collected from inside the timed process
+        with open(tpath) as f:
+            tk = json.load(f)["kernels"]
+        traffic = tk.get("k_decode_lanes", {}).get("hbm_bytes")
+        traffic_enc = tk.get("k_encode_fused", {}).get("hbm_bytes")
+
     if rank == 0:
         res = {
             "metric": "encode+decode GB/s (int16 in)",
@@ -208,14 +218,17 @@ def main():
             "compression_ratio": ratio,
             "encode_GBps": raw_bytes / (enc_ms[3] * 1e-3) / 1e9,
             "decode_GBps": raw_bytes / (dec_ms[3] * 1e-3) / 1e9,
-            "kernel_ms": {"encode_sizes": float(enc_ms[0]), "encode_scan": float(enc_ms[1]), "encode_pack": float(enc_ms[2]),
-                          "decode_walk": float(dec_ms[0]), "decode_kernel": float(dec_ms[1])},
+            # HIP events on the codec's stream.  encode: [state memset | - | k_encode_fused];
+            # decode: [granule memset | k_decode_lanes (header-chain walk fused in)]
+            "kernel_ms": {"encode_prepare": float(enc_ms[0] + enc_ms[1]), "encode_kernel": float(enc_ms[2]),
+                          "decode_prepare": float(dec_ms[0]), "decode_kernel": float(dec_ms[1])},
             "roofline": {"bound": "hbm", "kernel": "k_decode_lanes", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": dec_kernel_ms},
-            "roofline_encode": {"bound": "hbm", "kernel": "k_encode_pack", "achieved": algo_bytes / (pack_ms * 1e-3) / 1e9,
+            "roofline_encode": {"bound": "hbm", "kernel": "k_encode_fused", "achieved": algo_bytes / (pack_ms * 1e-3) / 1e9,
                                 "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                "frac": algo_bytes / (pack_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel_ms": pack_ms},
+                                "frac": algo_bytes / (pack_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic_enc,
+                                "kernel_ms": pack_ms},
         }
         if world == 1 and a.cpu_seconds > 0:
             nsamp = min(n_chunks, 64)

@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--decode-impl", type=int, default=5)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0: skip)")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; "
+                    "gloo only to rehearse the multi-rank flow on one GPU)")
     ap.add_argument("--debug-flags", type=int, default=0, help="kernel ablation switches (profiling only; results invalid)")
     return ap.parse_args()
 
@@ -120,8 +122,12 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            local = 0  # rehearsal: every rank on the one visible GPU
+            dist.init_process_group(a.backend)
     import deltarice_amd as dr
     from deltarice_amd import dist as drdist
 
@@ -148,8 +154,12 @@ def main():
         if collect is not None:
             collect["enc"].append(plan.last_timings())
         if world > 1:
-            with torch.cuda.stream(ctx.stream):
-                drdist.gather_encoded_sizes(off[-1])
+            if a.backend == "nccl":
+                with torch.cuda.stream(ctx.stream):
+                    drdist.gather_encoded_sizes(off[-1])
+            else:
+                ctx.stream.synchronize()
+                drdist.gather_encoded_sizes(off[-1].cpu())
         plan.decode_async(words, off, y)
         if collect is not None:
             collect["dec"].append(plan.last_timings())
@@ -176,7 +186,7 @@ def main():
     dt = time.perf_counter() - t0
     plan.finish()
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

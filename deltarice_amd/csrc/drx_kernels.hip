@@ -394,44 +394,44 @@ __device__ __forceinline__ int load8_dwords(const int16_t *__restrict__ x, uint3
     return nv;
 }
 
-// Bits of this lane's nv codes (nv == 8 for every lane of a full tile).
-template <bool FULL>
-__device__ __forceinline__ uint32_t lane_tile_bits(const PackedCodes &c, int nv) {
-    if (FULL) {
-        const u16x2 s = as_u16x2(c.nb[0]) + as_u16x2(c.nb[1]) + as_u16x2(c.nb[2]) + as_u16x2(c.nb[3]);
-        const uint32_t v = as_u32(s);
-        return (v & 0xffffu) + (v >> 16);
-    }
-    uint32_t bits = 0;
+// Zeroes the code lengths of the samples a lane does not have (trailing partial tile): a
+// zero-length code contributes no bits and, in emit_tile<false>, no set bits either.
+__device__ __forceinline__ void mask_tail(PackedCodes &c, int nv) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const uint32_t n0 = (2 * j < nv) ? (c.nb[j] & 0xffffu) : 0u;
-        const uint32_t n1 = (2 * j + 1 < nv) ? (c.nb[j] >> 16) : 0u;
-        bits += n0 + n1;
+        const uint32_t m = (2 * j + 1 < nv) ? 0xffffffffu : ((2 * j < nv) ? 0x0000ffffu : 0u);
+        c.nb[j] &= m;
     }
-    return bits;
 }
 
-// ORs this lane's codes into LDS.  pb = 8 * (byte address of the buffer's word 0) + bit position of
-// the lane's first code: (pb >> 3) & ~3 is the LDS byte address of the word holding that bit.
+// Bits of this lane's 8 codes.
+__device__ __forceinline__ uint32_t lane_tile_bits(const PackedCodes &c) {
+    const u16x2 s = as_u16x2(c.nb[0]) + as_u16x2(c.nb[1]) + as_u16x2(c.nb[2]) + as_u16x2(c.nb[3]);
+    const uint32_t v = as_u32(s);
+    return (v & 0xffffu) + (v >> 16);
+}
+
+// ORs this lane's codes into LDS.  pb = 8 * (LDS byte address of the buffer's word 0) + bit position
+// of the lane's first code, so (pb >> 3) & ~3 is the LDS byte address of the word holding that bit.
+// FULL = false: lengths may have been zeroed by mask_tail(); such codes must not set any bit.
 template <bool FULL>
-__device__ __forceinline__ void emit_tile(const PackedCodes &c, int nv, uint32_t pb) {
+__device__ __forceinline__ void emit_tile(const PackedCodes &c, uint32_t pb) {
     typedef uint32_t __attribute__((address_space(3))) lds_u32;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        if (FULL || j < nv) {
-            const uint32_t sh = (j & 1) ? 16u : 0u;
-            const uint32_t n = (j & 1) ? (c.nb[j >> 1] >> 16) : (c.nb[j >> 1] & 0xffffu);
-            const uint32_t r = (j & 1) ? (c.r[j >> 1] >> 16) : (c.r[j >> 1] & 0xffffu);
-            const uint32_t kk = (j & 1) ? (c.kk[j >> 1] >> 16) : (c.kk[j >> 1] & 0xffffu);
-            (void)sh;
-            const uint64_t code = (uint64_t)((1u << kk) | r);   // terminator + payload; the leading zeros are implicit
-            const uint64_t v = code << (64u - (pb & 31u) - n);  // code left-aligned at bit (pb & 31) of a 64-bit window
-            lds_u32 *w = (lds_u32 *)(uintptr_t)((pb >> 3) & ~3u);
-            __hip_atomic_fetch_or(w, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if ((uint32_t)v) __hip_atomic_fetch_or(w + 1, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            pb += n;
-        }
+        const uint32_t n = (j & 1) ? (c.nb[j >> 1] >> 16) : (c.nb[j >> 1] & 0xffffu);
+        const uint32_t r = (j & 1) ? (c.r[j >> 1] >> 16) : (c.r[j >> 1] & 0xffffu);
+        const uint32_t kk = (j & 1) ? (c.kk[j >> 1] >> 16) : (c.kk[j >> 1] & 0xffffu);
+        uint32_t code32 = (1u << kk) | r;  // terminator + payload; the leading zeros are implicit
+        if (!FULL) code32 = n ? code32 : 0u;
+        const uint32_t pe = pb + n;        // end of this code = start of the next
+        // left-align the code at bit (pb & 31) of a 64-bit window: shift = 64 - (pb & 31) - n,
+        // which is ((pb & 32) - pe) mod 64; v_lshlrev_b64 reads 6 bits of the shift
+        const uint64_t v = (uint64_t)code32 << (((pb & 32u) - pe) & 63u);
+        lds_u32 *w = (lds_u32 *)(uintptr_t)((pb >> 3) & ~3u);
+        __hip_atomic_fetch_or(w, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((uint32_t)v) __hip_atomic_fetch_or(w + 1, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        pb = pe;
     }
 }
 
@@ -478,44 +478,59 @@ __global__ __launch_bounds__(64 * kEncWaves) void k_encode_fused(Geom G, const i
     uint64_t P = 0;        // bits so far (wave uniform)
     bool fits = true;      // everything so far is in buf (wave uniform)
     uint32_t carry = 0;    // dword whose high half is the sample before the tile (x[-1] := 0, :53-54)
-    constexpr int kAhead = 2;  // tiles in flight: ~6 K cycles of packing cover one HBM round trip
-    uint32_t wq[kAhead][4];
-    int nvq[kAhead];
-#pragma unroll
-    for (int u = 0; u < kAhead; ++u) {
-        nvq[u] = 0;
-        if ((uint32_t)u * kTile < r.len) nvq[u] = load8_dwords(x, r.len, (uint32_t)u * kTile, lane, vec_ok, wq[u]);
-    }
-    auto process_tile = [&](const uint32_t (&w)[4], int nv, uint32_t t0) {
+    // Full tiles run in a loop without any masking, with the next tile's 16-byte load in flight
+    // while the current one is packed; the trailing partial tile (if any) takes the masked path once.
+    auto process_tile = [&](const uint32_t (&w)[4], int nv, auto full_tag) {
+        constexpr bool FULLT = decltype(full_tag)::value;
         uint32_t xprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[3], 0x138, 0xf, 0xf, false);  // wave_shr:1
         if (lane == 0) xprev = carry;
         carry = (uint32_t)__builtin_amdgcn_readlane((int)w[3], 63);
         PackedCodes c;
         packed_codes(w, xprev, k, c);
-        const bool full = t0 + kTile <= r.len;  // wave uniform: no lane needs masking
-        const uint32_t lane_bits = full ? lane_tile_bits<true>(c, 8) : lane_tile_bits<false>(c, nv);
+        if (!FULLT) mask_tail(c, nv);
+        const uint32_t lane_bits = lane_tile_bits(c);
         const uint32_t incl = wave_incl_scan_dpp(lane_bits);
         const uint32_t tile_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         if (fits && ((P + tile_bits + 31u) >> 5) < (uint64_t)kEncCapWords) {
-            const uint32_t pb = buf_bits + (uint32_t)P + incl - lane_bits;
-            if (full) emit_tile<true>(c, 8, pb); else emit_tile<false>(c, nv, pb);
+            emit_tile<FULLT>(c, buf_bits + (uint32_t)P + incl - lane_bits);
         } else {
             fits = false;
         }
         P += tile_bits;
     };
-#pragma unroll 1
-    for (uint32_t t0 = 0; t0 < r.len; t0 += kAhead * kTile) {
+    const uint32_t n_full = r.len / kTile;
+    {
+        // kDepth tiles of loads in flight, in kDepth fixed register sets (the loop is unrolled by
+        // kDepth so that no loaded-but-not-yet-arrived register is ever copied): with 4 waves per
+        // SIMD a tile takes ~2.6 K cycles of wall time, less than one HBM round trip under load.
+        constexpr int kDepth = 3;
+        const uint4 *xv = reinterpret_cast<const uint4 *>(x) + lane;  // tile t: xv[64 * t]
+        uint4 q[kDepth];
+        uint32_t t = 0;
+        if (vec_ok) {
 #pragma unroll
-        for (int u = 0; u < kAhead; ++u) {
-            const uint32_t tu = t0 + (uint32_t)u * kTile;
-            if (tu < r.len) {
-                const uint32_t w[4] = {wq[u][0], wq[u][1], wq[u][2], wq[u][3]};
-                const int nv = nvq[u];
-                const uint32_t tn = tu + kAhead * kTile;
-                if (tn < r.len) nvq[u] = load8_dwords(x, r.len, tn, lane, vec_ok, wq[u]);
-                process_tile(w, nv, tu);
+            for (int u = 0; u < kDepth; ++u) {
+                q[u] = make_uint4(0, 0, 0, 0);
+                if ((uint32_t)u < n_full) q[u] = xv[64 * (size_t)u];
             }
+#pragma unroll 1
+            for (; t < n_full; t += kDepth) {
+#pragma unroll
+                for (int u = 0; u < kDepth; ++u) {
+                    if (t + (uint32_t)u < n_full) {
+                        const uint32_t w[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+                        if (t + (uint32_t)u + kDepth < n_full) q[u] = xv[64 * (size_t)(t + u + kDepth)];
+                        process_tile(w, 8, std::true_type{});
+                    }
+                }
+            }
+            t = n_full;
+        }
+        // unaligned waveforms, and the trailing partial tile
+        for (uint32_t t0 = t * kTile; t0 < r.len; t0 += kTile) {
+            uint32_t w[4];
+            const int nv = load8_dwords(x, r.len, t0, lane, vec_ok, w);
+            process_tile(w, nv, std::false_type{});
         }
     }
     const uint32_t n = (uint32_t)((P + 31u) >> 5);  // payload words n_i
@@ -615,11 +630,12 @@ __global__ __launch_bounds__(64 * kEncWaves) void k_encode_fused(Geom G, const i
         carry = (uint32_t)__shfl((int)w[3], 63);
         PackedCodes c;
         packed_codes(w, xprev, k, c);
-        const uint32_t lane_bits = lane_tile_bits<false>(c, nv);
+        mask_tail(c, nv);
+        const uint32_t lane_bits = lane_tile_bits(c);
         const uint32_t incl = wave_incl_scan_dpp(lane_bits);
         const uint32_t tile_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         const uint64_t w0 = P >> 5;  // first staged word
-        emit_tile<false>(c, nv, buf_bits + (uint32_t)(P & 31u) + incl - lane_bits);
+        emit_tile<false>(c, buf_bits + (uint32_t)(P & 31u) + incl - lane_bits);
         P += tile_bits;
         wave_sync();
         const uint32_t nfull = (uint32_t)((P >> 5) - w0);

@@ -41,6 +41,7 @@ SIGNATURES = {
     "drx_ctx_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
     "drx_plan_create": (C.c_int, [_vp, _u64, C.POINTER(_u32), C.POINTER(_u32), _u32, C.POINTER(_vp)]),
     "drx_plan_create_uniform": (C.c_int, [_vp, _u64, _u32, _u32, _u32, C.POINTER(_vp)]),
+    "drx_plan_set_filter": (C.c_int, [_vp, _u32, C.POINTER(C.c_int32)]),
     "drx_plan_destroy": (None, [_vp]),
     "drx_plan_n_chunks": (_u64, [_vp]),
     "drx_plan_total_samples": (_u64, [_vp]),

@@ -86,12 +86,13 @@ class Context:
 
     def plan_uniform(self, n_chunks: int, chunk_samples: int, opts: Sequence[int] = ()) -> "Plan":
         o = parse_opts(opts)
-        if not _is_delta(o):
-            raise DeltaRiceError(5, "prediction filters other than [1,-1] are not on the device path yet")
         h = C.c_void_p()
         L = 0 if o.wave_len < 0 else int(o.wave_len)
         self._check(self.lib.drx_plan_create_uniform(self._h, n_chunks, chunk_samples, L, o.rice_k, C.byref(h)))
-        return Plan(self, h)
+        plan = Plan(self, h)
+        if not _is_delta(o):  # general prediction filter: GPU FIR/IIR kernels (correct, not tuned)
+            self._check(self.lib.drx_plan_set_filter(h, o.n_taps, o.taps))
+        return plan
 
     def plan(self, chunk_samples: Sequence[int], wave_lens: Sequence[int], rice_m: int = 8) -> "Plan":
         """Ragged batch: per-chunk sample counts and WaveformLengths (0 or -1: whole chunk)."""

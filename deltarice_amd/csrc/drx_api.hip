@@ -48,6 +48,7 @@ struct drx_plan {
     uint64_t *d_wave_off = nullptr;    // decode: absolute header position
     uint64_t *d_chunk_words = nullptr;
     uint64_t *d_scan = nullptr;        // look-back state of the single-pass encoder + ticket
+    int32_t *d_taps = nullptr;         // general prediction filter (nullptr: delta)
     DevStatus *d_status = nullptr;
     DevStatus *h_status = nullptr;  // pinned
     bool last_was_encode = false;
@@ -194,6 +195,7 @@ static void plan_free(drx_plan *p) {
     if (p->d_wave_off) (void)hipFree(p->d_wave_off);
     if (p->d_chunk_words) (void)hipFree(p->d_chunk_words);
     if (p->d_scan) (void)hipFree(p->d_scan);
+    if (p->d_taps) (void)hipFree(p->d_taps);
     if (p->d_status) (void)hipFree(p->d_status);
     if (p->h_status) (void)hipHostFree(p->h_status);
     for (hipEvent_t e : p->ev) if (e) (void)hipEventDestroy(e);
@@ -291,6 +293,24 @@ drx_status drx_plan_create_uniform(drx_ctx *ctx, uint64_t n_chunks, uint32_t chu
     return DRX_OK;
 }
 
+drx_status drx_plan_set_filter(drx_plan *p, uint32_t n_taps, const int32_t *taps) {
+    if (!p || !taps || n_taps == 0 || n_taps > DRX_MAX_TAPS) return DRX_ERR_ARG;
+    drx_ctx *ctx = p->ctx;
+    if (taps[0] == 0) return fail(ctx, DRX_ERR_ARG, "taps[0] must not be 0 (the inverse filter divides by it)");
+    DRX_HIP(ctx, hipSetDevice(ctx->device));
+    DRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_taps == 2 && taps[0] == 1 && taps[1] == -1) {  // checkIfDeltaFilter, src/deltaRice.c:38-46
+        p->G.n_taps = 0;
+        p->G.taps = nullptr;
+        return DRX_OK;
+    }
+    if (!p->d_taps) DRX_HIP(ctx, hipMalloc((void **)&p->d_taps, DRX_MAX_TAPS * sizeof(int32_t)));
+    DRX_HIP(ctx, hipMemcpy(p->d_taps, taps, n_taps * sizeof(int32_t), hipMemcpyHostToDevice));
+    p->G.n_taps = n_taps;
+    p->G.taps = p->d_taps;
+    return DRX_OK;
+}
+
 void drx_plan_destroy(drx_plan *p) { plan_free(p); }
 uint64_t drx_plan_n_chunks(const drx_plan *p) { return p ? p->G.n_chunks : 0; }
 uint64_t drx_plan_total_samples(const drx_plan *p) { return p ? p->total_samples : 0; }
@@ -315,7 +335,7 @@ drx_status drx_encode(drx_plan *p, const int16_t *d_in, uint32_t *d_out, uint64_
     drx_ctx *ctx = p->ctx;
     DRX_HIP(ctx, hipSetDevice(ctx->device));
     DRX_HIP(ctx, hipMemsetAsync(p->d_status, 0, sizeof(DevStatus), ctx->stream));
-    if (ctx->encode_impl == 1)
+    if (ctx->encode_impl == 1 && p->G.n_taps == 0)
         DRX_HIP(ctx, launch_encode_fused(p->G, d_in, d_out, out_cap_words, d_chunk_word_off, p->d_wave_words,
                                          p->d_scan, p->d_status, ctx->profile ? p->ev : nullptr, ctx->stream));
     else
@@ -335,7 +355,7 @@ drx_status drx_decode(drx_plan *p, const uint32_t *d_in, uint64_t in_words,
     DRX_HIP(ctx, hipMemsetAsync(p->d_status, 0, sizeof(DevStatus), ctx->stream));
     p->G.dbg = ctx->debug_flags;
     DRX_HIP(ctx, launch_decode(p->G, d_in, in_words, d_chunk_word_off, d_out, p->d_wave_off,
-                               p->d_wave_words, p->d_scan, p->d_status, ctx->decode_impl,
+                               p->d_wave_words, p->d_scan, p->d_status, p->G.n_taps ? 0 : ctx->decode_impl,
                                ctx->profile ? p->ev : nullptr, ctx->stream));
     p->ev_valid = ctx->profile != 0;
     p->last_was_encode = false;
@@ -386,8 +406,6 @@ drx_status drx_filter_chunk_host(drx_ctx *ctx, int reverse, size_t cd_nelmts, co
     drx_opts o;
     if (drx_parse_cd_values(cd_nelmts, cd_values, &o) != DRX_OK)
         return fail(ctx, DRX_ERR_ARG, "invalid compression_opts");
-    if (!(o.n_taps == 2 && o.taps[0] == 1 && o.taps[1] == -1))
-        return fail(ctx, DRX_ERR_UNSUPPORTED, "prediction filters other than [1,-1] are not on the device path yet");
     std::lock_guard<std::mutex> lock(ctx->mu);
     DRX_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->d_off) DRX_HIP(ctx, hipMalloc((void **)&ctx->d_off, 2 * sizeof(uint64_t)));
@@ -406,6 +424,7 @@ drx_status drx_filter_chunk_host(drx_ctx *ctx, int reverse, size_t cd_nelmts, co
     drx_plan *plan = nullptr;
     drx_status st = drx_plan_create_uniform(ctx, 1, n_samples, L, o.rice_k, &plan);
     if (st != DRX_OK) return st;
+    if ((st = drx_plan_set_filter(plan, o.n_taps, o.taps)) != DRX_OK) { drx_plan_destroy(plan); return st; }
     const size_t raw_bytes = (size_t)n_samples * 2;
     const size_t enc_cap_bytes = (size_t)plan->max_words * 4;
     void *result = nullptr;

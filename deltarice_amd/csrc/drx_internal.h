@@ -25,6 +25,11 @@ struct Geom {
     uint32_t uniform;  // all chunks share (n_samples, wave_len): pure arithmetic mapping
     uint32_t u_n_samples, u_wave_len, u_n_waves;
     uint32_t k;  // log2(M)
+    // prediction filter (src/deltaRice.c:49-76,78-103).  n_taps == 0: the default [1,-1] (delta), which
+    // the fast kernels implement; otherwise taps (device pointer, n_taps entries) select the general
+    // FIR / IIR kernels.
+    uint32_t n_taps;
+    const int32_t *taps;
     uint32_t dbg;  // ablation switches for profiling builds of the decode kernel (0 in normal use):
                    // bit 0: skip the output stores, bit 1: skip the stream loads
 };

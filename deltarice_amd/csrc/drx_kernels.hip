@@ -140,6 +140,14 @@ __device__ __forceinline__ void rice_code(int32_t d, uint32_t k, uint32_t &code,
     code = esc ? (0x10000u | z) : ((1u << k) | (z & ((1u << k) - 1u)));
 }
 
+// General prediction filter, forward (src/deltaRice.c:64-74): d[i] = sum_j taps[j] * x[i-j] over the
+// samples that exist, every partial sum truncated to int16 -- i.e. the sum mod 2^16.
+__device__ __forceinline__ int32_t fir_residual(const int16_t *__restrict__ x, uint32_t i, const Geom &G) {
+    uint32_t acc = 0;
+    for (uint32_t t = 0; t < G.n_taps && t <= i; ++t) acc += (uint32_t)((int32_t)x[i - t] * G.taps[t]);
+    return (int32_t)(int16_t)(uint16_t)acc;
+}
+
 // Pass A: payload word count n_i of every waveform.
 __global__ __launch_bounds__(256) void k_encode_sizes(Geom G, const int16_t *__restrict__ in,
                                                       uint32_t *__restrict__ wave_words) {
@@ -160,8 +168,9 @@ __global__ __launch_bounds__(256) void k_encode_sizes(Geom G, const int16_t *__r
         carry = __shfl(v[7], 63);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int32_t d = (int32_t)(int16_t)(v[j] - prev);
+            int32_t d = (int32_t)(int16_t)(v[j] - prev);
             prev = v[j];
+            if (G.n_taps) d = (j < nv) ? fir_residual(x, t0 + 8u * (uint32_t)lane + (uint32_t)j, G) : 0;
             uint32_t code, nb;
             rice_code(d, k, code, nb);
             bits += (j < nv) ? nb : 0u;
@@ -269,8 +278,9 @@ __global__ __launch_bounds__(256) void k_encode_pack(Geom G, const int16_t *__re
         uint32_t lane_bits = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int32_t d = (int32_t)(int16_t)(v[j] - prev);
+            int32_t d = (int32_t)(int16_t)(v[j] - prev);
             prev = v[j];
+            if (G.n_taps) d = (j < nv) ? fir_residual(x, t0 + 8u * (uint32_t)lane + (uint32_t)j, G) : 0;
             rice_code(d, k, code[j], nb[j]);
             if (j >= nv) nb[j] = 0;
             lane_bits += nb[j];
@@ -720,6 +730,7 @@ __global__ __launch_bounds__(64) void k_decode_simple(Geom G, const uint32_t *__
     uint64_t win = 0;
     uint32_t have = 0, wi = 0;
     int32_t acc = 0;
+    int16_t hist[64];  // general prediction filters only (lives in scratch; the delta path never touches it)
     for (uint32_t i = 0; i < r.len; ++i) {
         if (have <= 32u) {
             const uint32_t w = wi < n ? s[wi] : 0u;
@@ -733,7 +744,17 @@ __global__ __launch_bounds__(64) void k_decode_simple(Geom G, const uint32_t *__
         const uint64_t t = win << (q + 1u);
         const uint32_t rem = pl ? (uint32_t)(t >> (64u - pl)) : 0u;
         const uint32_t z = (q == 8u) ? rem : ((q << k) + rem);
-        acc += (int32_t)(z >> 1) ^ -(int32_t)(z & 1u);  // un-zig-zag (:172-177), running sum (:80-89)
+        const int32_t d = (int32_t)(z >> 1) ^ -(int32_t)(z & 1u);  // un-zig-zag (:172-177)
+        if (G.n_taps == 0) {
+            acc += d;  // running sum (:80-89)
+        } else {
+            // general inverse (:92-101): y[i] = (int16)((int16)(d[i] - sum_{j>=1} taps[j] y[i-j]) / taps[0]);
+            // the last 64 outputs live in a lane-private circular history (taps <= DRX_MAX_TAPS = 64)
+            uint32_t a = (uint32_t)(int32_t)(int16_t)d;
+            for (uint32_t j = 1; j < G.n_taps && j <= i; ++j) a -= (uint32_t)((int32_t)hist[(i - j) & 63u] * G.taps[j]);
+            acc = (int32_t)(int16_t)(uint16_t)a / G.taps[0];
+            hist[i & 63u] = (int16_t)acc;
+        }
         y[i] = (int16_t)acc;
         const uint32_t used = q + 1u + pl;
         win <<= used;

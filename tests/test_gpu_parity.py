@@ -50,8 +50,6 @@ IMPLS = [0, 1, 2, 3, 4, 5, 6]
 @pytest.mark.parametrize("name", golden_case_names())
 def test_golden_batch_api(ctx, O, golden, name):
     g = golden[name]
-    if not delta_only(g["opts"]):
-        pytest.skip("general prediction filter: not on the device path (SURVEY 8f rank 2)")
     x = O.decode_chunk(g["words"], g["opts"])
     plan = ctx.plan_uniform(1, x.size, g["opts"])
     enc, w, off = gpu_encode(ctx, plan, x)
@@ -65,7 +63,8 @@ def test_golden_batch_api(ctx, O, golden, name):
 
 
 @pytest.mark.parametrize("name", ["kat_docs", "config1_one_chunk", "leftover_20877", "uniform_default",
-                                  "arange_i16_delta", "cd1", "L5", "k15"])
+                                  "arange_i16_delta", "cd1", "L5", "k15", "uniform_identity",
+                                  "arange_i16_identity", "arange_u16_identity", "fir4", "fir_neg_lead"])
 def test_golden_filter_callback_semantics(ctx, O, golden, name):
     # the body of H5Z_filter_deltarice: host bytes in, host bytes out
     g = golden[name]
@@ -239,9 +238,8 @@ def test_bad_options_rejected(ctx):
             ctx.plan_uniform(1, 1024, opts)
     with pytest.raises(dr.DeltaRiceError):
         ctx.filter_chunk(np.zeros(3, np.uint8), (8, 2))  # odd byte count (src/deltaRice.c:394-397)
-    with pytest.raises(dr.DeltaRiceError) as e:
-        ctx.filter_chunk(np.zeros(1024, np.int16), (8, 1024, 1, 1))
-    assert e.value.status == 5  # general prediction filters: loudly unsupported, never a CPU fallback
+    with pytest.raises(dr.DeltaRiceError):
+        ctx.filter_chunk(np.zeros(1024, np.int16), (8, 1024, 2, 0, 1))  # taps[0] == 0: the inverse divides by it
 
 
 # --------------------------------------------------------------------------- size-independent properties
@@ -269,3 +267,21 @@ def test_large_batch_properties(ctx, O):
     enc2 = plan.encode(y)
     assert enc2.total_words == enc.total_words
     assert torch.equal(enc2.words[:enc2.total_words], enc.words[:enc.total_words])
+
+
+def test_general_prediction_filters_vs_oracle(ctx, O):
+    """cd_nelmts >= 3 (src/deltaRice.c:64-74,91-102): FIR forward / IIR inverse on the GPU, compared with the
+    oracle for taps the reference's own tests and docs use (tests/test.py:46-83, docs/Optimization.md:21)."""
+    rng = np.random.default_rng(77)
+    x = rng.normal(0, 40, 3 * 5000).astype(np.int16)
+    for taps in [(1,), (1, -1, 1, -1), (-1, 1), (1, -2, 1), (2, -1), (1, 0, 0, -1)]:
+        opts = (8, 1000, len(taps)) + tuple(t & 0xFFFFFFFF for t in taps)
+        ref_w, ref_off = O.encode_batch(x, 5000, opts)
+        plan = ctx.plan_uniform(3, 5000, opts)
+        enc = plan.encode(dev(ctx, x))
+        w, off = enc.to_numpy()
+        assert np.array_equal(off, ref_off) and np.array_equal(w, ref_w), taps
+        y = plan.decode(enc).cpu().numpy()
+        assert np.array_equal(y, O.decode_batch(ref_w, ref_off, 5000, opts)), taps  # lossy taps[0] included
+        if abs(taps[0]) == 1:
+            assert np.array_equal(y, x), taps

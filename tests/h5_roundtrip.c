@@ -1,7 +1,7 @@
 /* Test helper: drives filter 32025 through the real HDF5 library (C API), the way
  * /root/reference/examples/testCode.c:60-127 does, but loading the filter as a dynamic plugin
  * (HDF5_PLUGIN_PATH) instead of linking it.
- *   write    <file> <raw.bin> <rows> <cols> <chunk_rows> <M> <L>   H5Dwrite through the filter
+ *   write    <file> <raw.bin> <rows> <cols> <chunk_rows> [cd...]   H5Dwrite through the filter (any cd_values)
  *   read     <file> <out.bin>                                      H5Dread through the filter
  *   chunks   <file> <prefix>                                       stored bytes of every chunk (H5Dread_chunk)
  *   writeraw <file> <rows> <cols> <chunk_rows> <M> <L> <prefix>    H5Dwrite_chunk of pre-encoded chunks
@@ -26,18 +26,22 @@ static void *slurp(const char *path, size_t *n) {
     return p;
 }
 
-static hid_t make_dcpl(hsize_t chunk_rows, hsize_t cols, unsigned M, unsigned L) {
+static hid_t make_dcpl_n(hsize_t chunk_rows, hsize_t cols, size_t ncd, const unsigned *cd) {
     hid_t dcpl = H5Pcreate(H5P_DATASET_CREATE);
     hsize_t chunk[2] = {chunk_rows, cols};
-    const unsigned cd[2] = {M, L};
     H5Pset_chunk(dcpl, 2, chunk);
-    if (H5Pset_filter(dcpl, FILTER, H5Z_FLAG_MANDATORY, 2, cd) < 0) return -1;
+    if (H5Pset_filter(dcpl, FILTER, H5Z_FLAG_MANDATORY, ncd, cd) < 0) return -1;
     return dcpl;
+}
+
+static hid_t make_dcpl(hsize_t chunk_rows, hsize_t cols, unsigned M, unsigned L) {
+    const unsigned cd[2] = {M, L};
+    return make_dcpl_n(chunk_rows, cols, 2, cd);
 }
 
 int main(int argc, char **argv) {
     if (argc < 3) return 1;
-    if (!strcmp(argv[1], "write") && argc == 9) {
+    if (!strcmp(argv[1], "write") && argc >= 7) {
         hsize_t rows = strtoull(argv[4], 0, 10), cols = strtoull(argv[5], 0, 10), crows = strtoull(argv[6], 0, 10);
         size_t n;
         short *raw = slurp(argv[3], &n);
@@ -45,7 +49,10 @@ int main(int argc, char **argv) {
         hid_t file = H5Fcreate(argv[2], H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
         hsize_t dims[2] = {rows, cols};
         hid_t space = H5Screate_simple(2, dims, NULL);
-        hid_t dcpl = make_dcpl(crows, cols, (unsigned)atoi(argv[7]), (unsigned)atoi(argv[8]));
+        unsigned cd[80];
+        size_t ncd = 0;
+        for (int i = 7; i < argc && ncd < 80; ++i) cd[ncd++] = (unsigned)strtoul(argv[i], 0, 10);
+        hid_t dcpl = make_dcpl_n(crows, cols, ncd, cd);
         CHECK(dcpl);
         hid_t dset = H5Dcreate(file, "test", H5T_NATIVE_SHORT, space, H5P_DEFAULT, dcpl, H5P_DEFAULT);
         CHECK(dset);

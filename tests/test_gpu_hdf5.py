@@ -74,6 +74,39 @@ def test_hdf5_roundtrip_and_stored_bytes(h5tool, tmp_path, rows, cols, crows, M,
     assert np.array_equal(np.fromfile(back2, np.int16).reshape(rows, cols), x)
 
 
+# the six cases of the reference's tests/test.py (write -> close -> reopen -> read -> array_equal)
+REF_TESTS = [
+    ("worst_case", "uniform", ()),                      # tests/test.py:8-18
+    ("different_m", "uniform", (16,)),                  # :20-31
+    ("m_and_segment_length", "uniform", (8, 1024)),     # :33-44
+    ("different_filter", "uniform", (8, 1024, 1, 1)),   # :46-57
+    ("all_signed", "arange_i16", (8, 1024, 1, 1)),      # :59-70
+    ("all_unsigned", "arange_u16", (8, 1024, 1, 1)),    # :72-83
+]
+
+
+@pytest.mark.parametrize("name,kind,opts", REF_TESTS)
+def test_reference_test_suite_cases(h5tool, tmp_path, name, kind, opts):
+    from oracle import oracle as O
+    if kind == "uniform":
+        x = np.random.default_rng(len(opts)).uniform(-32768, 32768, size=2 ** 16).astype(np.int16)
+    elif kind == "arange_i16":
+        x = np.arange(-32768, 32768).astype(np.int16)
+    else:
+        x = np.arange(0, 65536).astype(np.uint16).view(np.int16)
+    rows, cols, crows = 8, 8192, 2  # the filter sees four 2 x 8192 sub-chunks, like h5py's auto-chunking
+    raw, h5, back = tmp_path / "raw.bin", tmp_path / "t.h5", tmp_path / "back.bin"
+    x.tofile(raw)
+    h5tool("write", h5, raw, rows, cols, crows, *opts)
+    h5tool("read", h5, back)
+    assert np.array_equal(np.fromfile(back, np.int16), x), f"Failed {name}"
+    n = int(h5tool("chunks", h5, tmp_path / "chunk").stdout)
+    for c in range(n):
+        stored = np.fromfile(f"{tmp_path}/chunk.{c}", np.uint32)
+        ref = O.encode_chunk(x.reshape(rows, cols)[c * crows:(c + 1) * crows], opts)
+        assert np.array_equal(stored, ref), f"{name}: chunk {c} differs from the oracle"
+
+
 def test_h5dump_sees_the_filter(h5tool, tmp_path):
     h5dump = os.path.join(HDF5_DIR, "bin", "h5dump")
     if not os.path.exists(h5dump):

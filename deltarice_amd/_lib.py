@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdeltarice_hip.so")
+# DRX_LIB_PATH: load another build of the same ABI (A/B timing of kernel variants on one GPU box)
+LIB_PATH = os.environ.get("DRX_LIB_PATH") or os.path.join(_HERE, "libdeltarice_hip.so")
 PLUGIN_PATH = os.path.join(_HERE, "plugin", "libh5deltarice.so")
 
 DRX_OK = 0

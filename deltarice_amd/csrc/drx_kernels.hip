@@ -801,7 +801,7 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
                                                      uint32_t *__restrict__ wave_words,
                                                      uint64_t *__restrict__ granules, uint32_t *__restrict__ ticket,
                                                      DevStatus *st, int16_t *__restrict__ out) {
-    static_assert(RW >= 2 * LW && (RW == 32 || RW == 64 || RW == 128) && (LW == 8 || LW == 16 || LW == 32), "ring");
+    static_assert(RW >= 2 * LW && (RW == 32 || RW == 64 || RW == 128) && (LW == 8 || LW == 16), "ring");
     constexpr int LOG_RW = RW == 32 ? 5 : (RW == 64 ? 6 : 7);
     constexpr int OSW = T / 2 + 4;  // output row stride in words (16-byte aligned rows)
     constexpr int PPS = T / 8;      // 16-byte pieces per stream per round
@@ -809,7 +809,6 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
     constexpr int NV = LW / 4;      // 16-byte loads per piece
     constexpr uint32_t WMASK = (1u << 27) - 1u;
     constexpr uint32_t NEED_AT = GS + 2;                                   // must refill below this many words
-    constexpr uint32_t ISSUE_AT = (RW - LW) > NEED_AT + 4 ? RW - LW - 2 : RW - LW;  // start prefetching here
     static_assert(T % GS == 0 && RW - LW >= GS + 2, "round length / ring slack");
     __shared__ uint32_t ring[(RW + 1) * 64];  // row r: word w with RW - (w mod RW) == r; row 0 mirrors row RW
     __shared__ __attribute__((aligned(16))) uint32_t obuf[64 * OSW];  // doubles as the start-up tables
@@ -819,6 +818,13 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
 
     const int lane = lane_id();
     const uint32_t k = G.k;
+    // Stores go through pointers with an explicit global address space: once `out` has travelled through
+    // nested by-reference lambda captures the compiler no longer infers it and emits flat_store, which
+    // also ticks lgkmcnt and serialises against the LDS traffic of the write-out (measured: 2x slower).
+    typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+    typedef u32x4v __attribute__((address_space(1))) g_uint4;
+    typedef int16_t __attribute__((address_space(1))) g_i16;
+    g_i16 *const outg = (g_i16 *)out;
     uint64_t g;
     bool active;
     uint32_t len = 0, n = 0;
@@ -899,8 +905,8 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
     typedef uint16_t __attribute__((may_alias)) u16a;
     u16a *myout = reinterpret_cast<u16a *>(obuf + lane * OSW);
 
-    auto load_piece = [&](uint4 (&v)[NV]) {
-        const uint64_t a = A + flw;
+    auto load_piece = [&](uint4 (&v)[NV], uint32_t ahead = 0) {
+        const uint64_t a = A + flw + ahead;
         if (in_vec_ok && a + (uint32_t)LW <= in_words) {
 #pragma unroll
             for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const uint4 *>(in + a + 4 * j);
@@ -927,17 +933,16 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
     };
 
     uint32_t Q = 0u - 32u * s0;  // minus the bit position (relative to A)
-    // Q_need / Q_issue: positions (in Q units, Q decreases) at which this lane must have /
-    // would like to have its next piece; 0x80000000 apart from Q means "never" (stream exhausted)
-    uint32_t Q_need, Q_issue;
-    auto set_limits = [&]() {
+    // Q_need: position (in Q units, Q decreases) at which this lane must have its next piece;
+    // 0x7fffffff away from Q means "never" (stream exhausted)
+    uint32_t Q_need;
+    auto set_limits = [&]() __attribute__((always_inline)) {
         // avail = flw - cw < X  <=>  cw > flw - X  <=>  Q <= ~(32 * (flw - X + 1) - 1) ... kept simple:
         // cw = (~Q) >> 5, so cw >= c  <=>  ~Q >= 32 c  <=>  Q <= ~(32 c)
         const bool more = flw < endw;
         Q_need = more ? ~(32u * (flw - NEED_AT + 1u)) : Q - 0x7fffffffu;
-        Q_issue = more ? ~(32u * (flw - ISSUE_AT)) : Q - 0x7fffffffu;
     };
-    auto sync_refill = [&]() {  // serve every lane that is (nearly) dry, waiting for the data
+    auto sync_refill = [&]() __attribute__((always_inline)) {  // serve every lane that is (nearly) dry, waiting for the data
         for (;;) {
             const uint32_t avail = (flw - ((~Q) >> 5)) & WMASK;
             const bool more = flw < endw;
@@ -965,7 +970,7 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
     }
     int32_t acc = 0;
 
-    auto decode_group = [&](auto first_tag, int tg) {
+    auto decode_group = [&](auto first_tag, int tg) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_tag)::value;
 #pragma unroll
         for (int u = 0; u < GS; ++u) {
@@ -992,14 +997,14 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
         }
     };
 
-    auto write_out = [&](uint32_t t0) {
+    auto write_out = [&](uint32_t t0) __attribute__((always_inline)) {
         if (G.dbg & 1u) return;
         if (t0 >= lo_max && t0 + T <= hi_min) {  // interior round: whole aligned lines only
 #pragma unroll
             for (int i = 0; i < PPS; ++i) {
                 const int st = i * SPI + lane / PPS, p = lane % PPS;
                 const uint4 v = *reinterpret_cast<const uint4 *>(obuf + st * OSW + 4 * p);
-                *reinterpret_cast<uint4 *>(out + wo_off[i] + t0) = v;
+                *(g_uint4 *)(outg + wo_off[i] + t0) = (u32x4v){v.x, v.y, v.z, v.w};
             }
         } else {
 #pragma unroll
@@ -1008,9 +1013,9 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
                 const uint32_t tpos = t0 + 8u * (uint32_t)p;  // step index of the piece's first sample
                 if (tpos + 8u > wo_lo[i] && tpos < wo_hi[i]) {
                     const uint4 v = *reinterpret_cast<const uint4 *>(obuf + st * OSW + 4 * p);
-                    int16_t *dst = out + wo_off[i] + t0;
+                    g_i16 *dst = outg + wo_off[i] + t0;
                     if (tpos >= wo_lo[i] && tpos + 8u <= wo_hi[i]) {
-                        *reinterpret_cast<uint4 *>(dst) = v;
+                        *(g_uint4 *)dst = (u32x4v){v.x, v.y, v.z, v.w};
                     } else {
                         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -1035,42 +1040,70 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
         wave_sync();
     }
 
-    // steady state
-    uint4 pv[NV];        // piece in flight
-    bool pneed = false;  // this lane has one in flight
-    bool pend = false;   // some lane has (wave uniform)
-    set_limits();
-    for (uint32_t t0 = T; t0 < steps; t0 += T) {
+    // steady state.  Stream pieces are requested at the END of a round, just BEFORE the round's stores
+    // are issued, and written to the ring at the end of the next round.  vmcnt retires in issue order
+    // and counts loads and stores together, so a wait for loads that are OLDER than the PPS stores of
+    // their own round is `s_waitcnt vmcnt(PPS)` and never waits for those stores (ablation: loads alone
+    // +0.04 ms, stores alone +0.11 ms, both +1.0 ms when the commit had to drain the stores too).
+    // The interior rounds (every stream fully inside its waveform: whole-line stores only) run in a
+    // loop of their own whose only vector-memory operations are those loads and those PPS stores, so
+    // that the compiler's waitcnt insertion can prove the count.  Up to two pieces per lane and round
+    // (2 LW words = 16 bits per sample at LW = 16); hungrier streams fall back to sync_refill().
+    auto edge_round = [&](uint32_t t0) __attribute__((always_inline)) {  // first / last rounds: masked stores, synchronous refills
 #pragma unroll 1
         for (int tg = 0; tg < T; tg += GS) {
-            // refill policy: one signed compare per test (positions are mod 2^32)
-            if (pend && __any((int32_t)(Q - Q_need) <= 0)) {
-                if (pneed) { if (!(G.dbg & 2u)) store_piece(pv); else flw += (uint32_t)LW; }
-                pneed = false; pend = false;
+            sync_refill();
+            decode_group(std::false_type{}, tg);
+        }
+        wave_sync();
+        write_out(t0);
+        wave_sync();
+    };
+    uint32_t t0 = T;
+    for (; t0 < steps && !(t0 >= lo_max && t0 + T <= hi_min); t0 += T) edge_round(t0);
+
+    uint4 pv0[NV], pv1[NV];               // pieces in flight
+    bool pneed0 = false, pneed1 = false;  // this lane has them in flight
+    set_limits();
+    for (; t0 + T <= hi_min && t0 < steps; t0 += T) {  // interior rounds
+#pragma unroll 1
+        for (int tg = 0; tg < T; tg += GS) {
+            if (__any((int32_t)(Q - Q_need) <= 0)) {  // one signed compare per test (positions are mod 2^32)
+                if (pneed0) store_piece(pv0);
+                if (pneed1) store_piece(pv1);
+                pneed0 = pneed1 = false;
                 wave_sync();
+                sync_refill();
                 set_limits();
-            }
-            if (!pend) {
-                if (__any((int32_t)(Q - Q_need) <= 0)) { sync_refill(); set_limits(); }
-                if (__any((int32_t)(Q - Q_issue) <= 0)) {
-                    const uint32_t avail = (flw - ((~Q) >> 5)) & WMASK;
-                    pneed = (flw < endw) && avail <= (uint32_t)(RW - LW);
-                    if (pneed && !(G.dbg & 2u)) load_piece(pv);
-                    pend = true;
-                }
             }
             decode_group(std::false_type{}, tg);
         }
         wave_sync();
-        if (pend) {  // commit before this round's stores are issued
-            if (pneed) { if (!(G.dbg & 2u)) store_piece(pv); else flw += (uint32_t)LW; }
-            pneed = false; pend = false;
-            wave_sync();
-            set_limits();
+        if (pneed0) store_piece(pv0);  // loads of the previous round end: older than that round's PPS stores
+        if (pneed1) store_piece(pv1);
+        wave_sync();
+        set_limits();
+        {
+            const uint32_t avail = (flw - ((~Q) >> 5)) & WMASK;
+            pneed0 = (flw < endw) && avail <= (uint32_t)(RW - LW) && !(G.dbg & 2u);
+            pneed1 = pneed0 && (flw + (uint32_t)LW < endw) && avail + (uint32_t)LW <= (uint32_t)(RW - LW);
+            if (pneed0) load_piece(pv0);
+            if (pneed1) load_piece(pv1, (uint32_t)LW);
         }
-        write_out(t0);
+        if (!(G.dbg & 1u)) {
+#pragma unroll
+            for (int i = 0; i < PPS; ++i) {  // whole aligned lines only
+                const int st = i * SPI + lane / PPS, p = lane % PPS;
+                const uint4 v = *reinterpret_cast<const uint4 *>(obuf + st * OSW + 4 * p);
+                *(g_uint4 *)(outg + wo_off[i] + t0) = (u32x4v){v.x, v.y, v.z, v.w};
+            }
+        }
         wave_sync();
     }
+    if (pneed0) store_piece(pv0);
+    if (pneed1) store_piece(pv1);
+    wave_sync();
+    for (; t0 < steps; t0 += T) edge_round(t0);
 }
 
 // ---------------------------------------------------------------------------
@@ -1147,7 +1180,7 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
             case 0: k_decode_simple<<<nb, 64, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_out); break;
             case 2: k_decode_lanes<32, 16, 64, 8, false><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
             case 3: k_decode_lanes<32, 8, 64, 8, false><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
-            case 4: k_decode_lanes<64, 32, 64, 16, false><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
+            case 4: k_decode_lanes<128, 16, 64, 16, false><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
             default: k_decode_lanes<64, 16, 64, 16, false><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
         }
     }

@@ -835,6 +835,7 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
         tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
         const uint32_t n_walk = (uint32_t)((G.n_chunks + 63u) >> 6);
         if (tk < n_walk) {  // walker role
+            __builtin_amdgcn_s_setprio(3);  // the chain is the critical path of the whole launch (A/B: -2.5 %)
             const uint64_t c = (uint64_t)tk * 64u + lane;
             if (c < G.n_chunks) walk_chunk(G, c, in, in_words, chunk_word_off, wave_off, wave_words, granules, st);
             return;

@@ -190,6 +190,16 @@ class Plan:
         self.finish()
         return y
 
+    def estimate_words(self, x: torch.Tensor) -> np.ndarray:
+        """Exact encoded size (uint32 words) of this batch for RiceParameter 2^k, k = 0..15 -- the
+        optimisation the reference's docs/Optimization.md describes; argmin gives the best m."""
+        self._dev_check(x, torch.int16, self.total_samples, "x")
+        cur = torch.cuda.current_stream(self.ctx.device)
+        self.ctx.stream.wait_stream(cur)
+        out = (C.c_uint64 * 16)()
+        self.ctx._check(self.ctx.lib.drx_estimate_words(self._h, x.data_ptr(), out))
+        return np.array(list(out), dtype=np.uint64)
+
     def last_timings(self):
         """Kernel times (ms) of the last call, HIP events on the context's stream; needs
         ctx.set_option("profile", 1).  encode: (sizes, scan, pack, total); decode: (walk, decode, 0, total)."""

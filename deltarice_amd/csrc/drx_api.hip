@@ -209,7 +209,7 @@ static drx_status plan_alloc(drx_ctx *ctx, drx_plan *p) {
     DRX_HIP(ctx, hipMalloc((void **)&p->d_wave_rel, W * sizeof(uint32_t)));
     DRX_HIP(ctx, hipMalloc((void **)&p->d_wave_off, W * sizeof(uint64_t)));
     DRX_HIP(ctx, hipMalloc((void **)&p->d_chunk_words, (p->G.n_chunks + 1) * sizeof(uint64_t)));
-    DRX_HIP(ctx, hipMalloc((void **)&p->d_scan, (W + 2) * sizeof(uint64_t)));
+    DRX_HIP(ctx, hipMalloc((void **)&p->d_scan, (W + 18) * sizeof(uint64_t)));
     DRX_HIP(ctx, hipMalloc((void **)&p->d_status, sizeof(DevStatus)));
     DRX_HIP(ctx, hipHostMalloc((void **)&p->h_status, sizeof(DevStatus), hipHostMallocDefault));
     memset(p->h_status, 0, sizeof(DevStatus));
@@ -359,6 +359,18 @@ drx_status drx_decode(drx_plan *p, const uint32_t *d_in, uint64_t in_words,
                                ctx->profile ? p->ev : nullptr, ctx->stream));
     p->ev_valid = ctx->profile != 0;
     p->last_was_encode = false;
+    return DRX_OK;
+}
+
+drx_status drx_estimate_words(drx_plan *p, const int16_t *d_in, uint64_t words_out[16]) {
+    if (!p || !d_in || !words_out) return DRX_ERR_ARG;
+    drx_ctx *ctx = p->ctx;
+    DRX_HIP(ctx, hipSetDevice(ctx->device));
+    // the look-back scratch is idle outside drx_encode/drx_decode: its first 16 words hold the sums
+    DRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DRX_HIP(ctx, launch_estimate_words(p->G, d_in, (unsigned long long *)p->d_scan, ctx->stream));
+    DRX_HIP(ctx, hipMemcpyAsync(words_out, p->d_scan, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    DRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return DRX_OK;
 }
 

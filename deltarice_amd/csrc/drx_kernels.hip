@@ -180,6 +180,49 @@ __global__ __launch_bounds__(256) void k_encode_sizes(Geom G, const int16_t *__r
     if (lane == 0) wave_words[g] = (uint32_t)((total + 31u) >> 5);
 }
 
+// RiceParameter optimiser (the routine docs/Optimization.md:5-19 describes but the reference does not
+// ship): exact size of the encoded batch for every k = 0..15 in one pass over the samples.
+// words[k] += 1 + ceil(bits_k / 32) per waveform (+1 per chunk); one wavefront per waveform.
+__global__ __launch_bounds__(256) void k_estimate_words(Geom G, const int16_t *__restrict__ in,
+                                                        unsigned long long *__restrict__ words) {
+    const int lane = lane_id();
+    const uint64_t g = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (g >= G.total_waves) return;
+    const WaveRef r = locate(G, g);
+    const int16_t *x = in + r.sample_off;
+    const bool vec_ok = ((uintptr_t)x & 15u) == 0;
+    uint32_t bits[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) bits[k] = 0;
+    int32_t carry = 0;
+    for (uint32_t t0 = 0; t0 < r.len; t0 += kTile) {
+        int32_t v[8];
+        const int nv = load8(x, r.len, t0, lane, vec_ok, v);
+        int32_t prev = __shfl_up(v[7], 1);
+        if (lane == 0) prev = carry;
+        carry = __shfl(v[7], 63);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int32_t d = (int32_t)(int16_t)(v[j] - prev);
+            prev = v[j];
+            if (G.n_taps) d = (j < nv) ? fir_residual(x, t0 + 8u * (uint32_t)lane + (uint32_t)j, G) : 0;
+            const uint32_t z = (uint32_t)((d << 1) ^ (d >> 31));
+            if (j < nv) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const uint32_t q = z >> k;
+                    bits[k] += q < 8u ? q + 1u + (uint32_t)k : 25u;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const uint64_t total = wave_sum_u64(bits[k]);
+        if (lane == 0) atomicAdd(words + k, (unsigned long long)(1u + ((total + 31u) >> 5) + (r.idx == 0 ? 1u : 0u)));
+    }
+}
+
 // Per chunk: position of each waveform's header word relative to the chunk start
 // (1 + exclusive prefix of (1 + n_i)) and the chunk's total word count.
 __global__ __launch_bounds__(256) void k_chunk_scan(Geom G, const uint32_t *__restrict__ wave_words,
@@ -1116,6 +1159,13 @@ static inline unsigned blocks_for(uint64_t items, unsigned per_block) {
 
 static inline void mark(hipEvent_t *ev, int i, hipStream_t s) {
     if (ev) (void)hipEventRecord(ev[i], s);
+}
+
+hipError_t launch_estimate_words(const Geom &G, const int16_t *d_in, unsigned long long *d_words16, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(d_words16, 0, 16 * sizeof(unsigned long long), s);
+    if (e != hipSuccess || G.total_waves == 0) return e;
+    k_estimate_words<<<blocks_for(G.total_waves, 4), 256, 0, s>>>(G, d_in, d_words16);
+    return hipGetLastError();
 }
 
 // Single-pass encode (k_encode_fused).  d_scan: uint64[total_waves] + one uint32 ticket

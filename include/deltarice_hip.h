@@ -109,6 +109,11 @@ drx_status drx_encode(drx_plan *plan, const int16_t *d_in, uint32_t *d_out, uint
 drx_status drx_decode(drx_plan *plan, const uint32_t *d_in, uint64_t in_words,
                       const uint64_t *d_chunk_word_off, int16_t *d_out);
 
+/* RiceParameter optimiser (docs/Optimization.md:5-19 of the reference describes one, the tree does not
+ * contain it): exact number of uint32 words drx_encode would emit for this batch with RiceParameter
+ * 2^k, for every k = 0..15 (host array of 16), in one pass over the samples.  Synchronous. */
+drx_status drx_estimate_words(drx_plan *plan, const int16_t *d_in, uint64_t words_out[16]);
+
 /* Waits for the plan's last encode/decode, reports device-side errors and (for
  * encode) the number of words produced.  total_words may be NULL. */
 drx_status drx_plan_finish(drx_plan *plan, uint64_t *total_words);

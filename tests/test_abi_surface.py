@@ -75,3 +75,30 @@ def test_python_h5_module_surface():
     from deltarice_amd import h5
     assert h5.H5FILTER == 32025
     assert callable(h5.register_h5_filter)
+
+
+def test_filter_callback_fails_loudly_without_gpu(capfd):
+    """No GPU in this container: the H5Z callback must report failure the HDF5 way (return 0, buffers
+    untouched) and say why -- it must not fall back to any CPU codec."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from deltarice_amd import PLUGIN_PATH
+    p = C.CDLL(PLUGIN_PATH)
+    p.H5Z_filter_deltarice.restype = C.c_size_t
+    p.H5Z_filter_deltarice.argtypes = [C.c_uint, C.c_size_t, C.POINTER(C.c_uint), C.c_size_t,
+                                       C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    buf = C.c_void_p(libc.malloc(4096))
+    C.memset(buf, 0, 4096)
+    size = C.c_size_t(4096)
+    cd = (C.c_uint * 2)(8, 1024)
+    before = buf.value
+    ret = p.H5Z_filter_deltarice(0, 2, cd, 2048, C.byref(size), C.byref(buf))
+    assert ret == 0 and buf.value == before and size.value == 4096
+    assert "deltarice" in capfd.readouterr().err
+    libc.free(buf)
+    from deltarice_amd import codec, DeltaRiceError
+    with pytest.raises(DeltaRiceError):
+        codec.Context(0)

@@ -285,3 +285,15 @@ def test_general_prediction_filters_vs_oracle(ctx, O):
         assert np.array_equal(y, O.decode_batch(ref_w, ref_off, 5000, opts)), taps  # lossy taps[0] included
         if abs(taps[0]) == 1:
             assert np.array_equal(y, x), taps
+
+
+def test_rice_parameter_optimiser_is_exact(ctx, O):
+    rng = np.random.default_rng(31)
+    x = (rng.standard_t(3, 4 * 6000) * 25).clip(-32768, 32767).astype(np.int16)
+    plan = ctx.plan_uniform(4, 6000, (8, 1500))
+    est = plan.estimate_words(dev(ctx, x))
+    for k in range(1, 16):
+        ref_w, _ = O.encode_batch(x, 6000, (1 << k, 1500))
+        assert int(est[k]) == ref_w.size, k
+    best = int(np.argmin(est[1:])) + 1
+    assert est[best] <= est[3]

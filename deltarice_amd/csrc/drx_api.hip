@@ -34,6 +34,11 @@ struct drx_ctx {
     void *d_enc = nullptr;   size_t enc_cap = 0;
     uint64_t *d_off = nullptr;
     void *h_pin = nullptr;   size_t pin_cap = 0;
+    // the host path's plan is kept between calls: HDF5 calls the filter once per chunk with the same
+    // geometry, and creating a plan costs eight hipMalloc/hipFree pairs (about a millisecond)
+    drx_plan *host_plan = nullptr;
+    uint32_t hp_samples = 0, hp_L = 0, hp_k = 0, hp_ntaps = 0;
+    int32_t hp_taps[DRX_MAX_TAPS] = {0};
     std::mutex mu;
 };
 
@@ -143,9 +148,12 @@ drx_status drx_ctx_create(int device, void *hip_stream, drx_ctx **out) {
     return DRX_OK;
 }
 
+static void plan_free(drx_plan *p);
+
 void drx_ctx_destroy(drx_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->host_plan) plan_free(c->host_plan);
     if (c->d_raw) (void)hipFree(c->d_raw);
     if (c->d_enc) (void)hipFree(c->d_enc);
     if (c->d_off) (void)hipFree(c->d_off);
@@ -433,10 +441,18 @@ drx_status drx_filter_chunk_host(drx_ctx *ctx, int reverse, size_t cd_nelmts, co
         if (n_samples == 0 || n_samples > 0x7fffffffu) return fail(ctx, DRX_ERR_CORRUPT, "bad sample count in header");
     }
     const uint32_t L = (o.wave_len < 0) ? 0u : (uint32_t)o.wave_len;
-    drx_plan *plan = nullptr;
-    drx_status st = drx_plan_create_uniform(ctx, 1, n_samples, L, o.rice_k, &plan);
-    if (st != DRX_OK) return st;
-    if ((st = drx_plan_set_filter(plan, o.n_taps, o.taps)) != DRX_OK) { drx_plan_destroy(plan); return st; }
+    drx_status st = DRX_OK;
+    if (!ctx->host_plan || ctx->hp_samples != n_samples || ctx->hp_L != L || ctx->hp_k != o.rice_k ||
+        ctx->hp_ntaps != o.n_taps || memcmp(ctx->hp_taps, o.taps, o.n_taps * sizeof(int32_t)) != 0) {
+        if (ctx->host_plan) { plan_free(ctx->host_plan); ctx->host_plan = nullptr; }
+        drx_plan *np = nullptr;
+        if ((st = drx_plan_create_uniform(ctx, 1, n_samples, L, o.rice_k, &np)) != DRX_OK) return st;
+        if ((st = drx_plan_set_filter(np, o.n_taps, o.taps)) != DRX_OK) { plan_free(np); return st; }
+        ctx->host_plan = np;
+        ctx->hp_samples = n_samples; ctx->hp_L = L; ctx->hp_k = o.rice_k; ctx->hp_ntaps = o.n_taps;
+        memcpy(ctx->hp_taps, o.taps, sizeof ctx->hp_taps);
+    }
+    drx_plan *plan = ctx->host_plan;
     const size_t raw_bytes = (size_t)n_samples * 2;
     const size_t enc_cap_bytes = (size_t)plan->max_words * 4;
     void *result = nullptr;
@@ -473,7 +489,6 @@ drx_status drx_filter_chunk_host(drx_ctx *ctx, int reverse, size_t cd_nelmts, co
             *out_bytes = raw_bytes;
         }
     } while (0);
-    drx_plan_destroy(plan);
     if (st != DRX_OK) { free(result); return st; }
     *out = result;
     return DRX_OK;

@@ -54,6 +54,8 @@ struct drx_plan {
     uint64_t *d_chunk_words = nullptr;
     uint64_t *d_scan = nullptr;        // look-back state of the single-pass encoder + ticket
     int32_t *d_taps = nullptr;         // general prediction filter (nullptr: delta)
+    uint32_t *d_walk_lists = nullptr;  // ragged plans: chunk indices, short-waveform chunks first
+    uint32_t n_short = 0, n_long = 0;
     DevStatus *d_status = nullptr;
     DevStatus *h_status = nullptr;  // pinned
     bool last_was_encode = false;
@@ -204,6 +206,7 @@ static void plan_free(drx_plan *p) {
     if (p->d_chunk_words) (void)hipFree(p->d_chunk_words);
     if (p->d_scan) (void)hipFree(p->d_scan);
     if (p->d_taps) (void)hipFree(p->d_taps);
+    if (p->d_walk_lists) (void)hipFree(p->d_walk_lists);
     if (p->d_status) (void)hipFree(p->d_status);
     if (p->h_status) (void)hipHostFree(p->h_status);
     for (hipEvent_t e : p->ev) if (e) (void)hipEventDestroy(e);
@@ -264,6 +267,14 @@ drx_status drx_plan_create(drx_ctx *ctx, uint64_t n_chunks, const uint32_t *chun
     if (st == DRX_OK && !uniform) {
         hipError_t e = hipMalloc((void **)&p->d_chunks, n_chunks * sizeof(ChunkDesc));
         if (e == hipSuccess) e = hipMemcpy(p->d_chunks, desc.data(), n_chunks * sizeof(ChunkDesc), hipMemcpyHostToDevice);
+        // walk lists: chunks of short waveforms are walked through LDS, the others hop by hop
+        std::vector<uint32_t> lists;
+        for (uint64_t c = 0; c < n_chunks; ++c) if (desc[c].wave_len <= kWalkShortLenHost) lists.push_back((uint32_t)c);
+        p->n_short = (uint32_t)lists.size();
+        for (uint64_t c = 0; c < n_chunks; ++c) if (desc[c].wave_len > kWalkShortLenHost) lists.push_back((uint32_t)c);
+        p->n_long = (uint32_t)lists.size() - p->n_short;
+        if (e == hipSuccess) e = hipMalloc((void **)&p->d_walk_lists, lists.size() * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemcpy(p->d_walk_lists, lists.data(), lists.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
         if (e != hipSuccess) st = fail(ctx, DRX_ERR_DEVICE, "chunk table upload failed: %s", hipGetErrorString(e));
     }
     if (st != DRX_OK) { plan_free(p); return st; }
@@ -364,7 +375,8 @@ drx_status drx_decode(drx_plan *p, const uint32_t *d_in, uint64_t in_words,
     p->G.dbg = ctx->debug_flags;
     DRX_HIP(ctx, launch_decode(p->G, d_in, in_words, d_chunk_word_off, d_out, p->d_wave_off,
                                p->d_wave_words, p->d_scan, p->d_status, p->G.n_taps ? 0 : ctx->decode_impl,
-                               ctx->profile ? p->ev : nullptr, ctx->stream));
+                               p->d_walk_lists, p->n_short, p->d_walk_lists ? p->d_walk_lists + p->n_short : nullptr,
+                               p->n_long, ctx->profile ? p->ev : nullptr, ctx->stream));
     p->ev_valid = ctx->profile != 0;
     p->last_was_encode = false;
     return DRX_OK;

@@ -57,7 +57,9 @@ hipError_t launch_encode_fused(const Geom &G, const int16_t *d_in, uint32_t *d_o
 hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                          const uint64_t *d_chunk_word_off, int16_t *d_out, uint64_t *d_wave_off,
                          uint32_t *d_wave_words, uint64_t *d_granules, DevStatus *d_status, int impl,
+                         const uint32_t *d_short_list, uint32_t n_short, const uint32_t *d_long_list, uint32_t n_long,
                          hipEvent_t *ev, hipStream_t s);
+constexpr uint32_t kWalkShortLenHost = 2048;  // keep equal to kWalkShortLen in drx_kernels.hip
 
 }  // namespace drx
 #endif

@@ -757,6 +757,117 @@ __global__ __launch_bounds__(64) void k_walk(Geom G, const uint32_t *__restrict_
     walk_chunk(G, c, in, in_words, chunk_word_off, wave_off, wave_words, nullptr, st);
 }
 
+__global__ __launch_bounds__(64) void k_walk_list(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
+                                                  const uint64_t *__restrict__ chunk_word_off,
+                                                  const uint32_t *__restrict__ chunk_list, uint32_t n_list,
+                                                  uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
+                                                  DevStatus *st) {
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    if (i >= n_list) return;
+    walk_chunk(G, chunk_list[i], in, in_words, chunk_word_off, wave_off, wave_words, nullptr, st);
+}
+
+// Header-chain walk for chunks of SHORT waveforms (one wavefront per chunk).  With n_i of a few
+// hundred words a chunk holds tens of thousands of waveforms and the per-hop HBM round trip of
+// walk_chunk() adds up to tens of milliseconds (27 343 hops for 14 M samples at L = 512).  Here the
+// wave streams the chunk through a 16 KB LDS block with coalesced 16-byte loads and lane 0 chases the
+// chain inside LDS (~0.07 us per hop); the price is one extra read of the chunk's stream.
+constexpr uint32_t kWalkBlockWords = 4096;
+constexpr uint32_t kWalkShortLen = 2048;  // WaveformLength up to which a chunk is walked through LDS
+
+constexpr uint32_t kWalkHopCap = 1024;   // hops buffered in LDS between coalesced flushes
+
+__global__ __launch_bounds__(64) void k_walk_block(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
+                                                   const uint64_t *__restrict__ chunk_word_off,
+                                                   const uint32_t *__restrict__ chunk_list, uint32_t n_list,
+                                                   uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
+                                                   DevStatus *st) {
+    constexpr uint32_t B = kWalkBlockWords;
+    constexpr int NV = B / 256;  // 16-byte loads per lane and block
+    __shared__ __attribute__((aligned(16))) uint32_t blk[B];
+    __shared__ __attribute__((aligned(8))) uint2 hop[kWalkHopCap];  // {position in the block, n}
+    if (blockIdx.x >= n_list) return;
+    const uint64_t c = chunk_list ? chunk_list[blockIdx.x] : blockIdx.x;
+    const int lane = lane_id();
+    uint64_t base;
+    uint32_t W, L, N;
+    if (G.uniform) { base = c * G.u_n_waves; W = G.u_n_waves; L = G.u_wave_len; N = G.u_n_samples; }
+    else { const ChunkDesc d = G.chunks[c]; base = d.wave_base; W = d.n_waves; L = d.wave_len; N = d.n_samples; }
+    const uint64_t begin = chunk_word_off[c];
+    uint64_t end = chunk_word_off[c + 1];
+    bool bad = false;
+    if (end > in_words || begin + 2 > end) { bad = true; end = begin; }
+    if (!bad && in[begin] != N) bad = true;
+    const uint32_t max_full = (uint32_t)(((uint64_t)L * 25u + 31u) >> 5);
+    const uint32_t max_last = W ? (uint32_t)(((uint64_t)(N - (W - 1) * L) * 25u + 31u) >> 5) : 0u;
+    // blocks on a fixed grid from g0 (16-byte aligned when the stream is), so that block k + 1 can be
+    // requested before the chase through block k starts
+    const bool vec_ok = ((uintptr_t)in & 15u) == 0;
+    const uint64_t g0 = begin & ~3ull;
+    uint64_t at = begin + 1;  // header of waveform w (wave uniform)
+    uint32_t w = 0;
+    uint4 pre[NV];
+    uint64_t pre_b0 = ~0ull;  // block the registers hold
+    auto request = [&](uint64_t b0) __attribute__((always_inline)) {
+        pre_b0 = b0;
+        if (vec_ok && b0 + B <= end) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) pre[j] = *reinterpret_cast<const uint4 *>(in + b0 + (uint32_t)(j * 64 + lane) * 4u);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const uint64_t i = b0 + (uint32_t)(j * 64 + lane) * 4u;
+                uint4 v;
+                v.x = (i + 0u < end) ? in[i + 0u] : 0u;
+                v.y = (i + 1u < end) ? in[i + 1u] : 0u;
+                v.z = (i + 2u < end) ? in[i + 2u] : 0u;
+                v.w = (i + 3u < end) ? in[i + 3u] : 0u;
+                pre[j] = v;
+            }
+        }
+    };
+    if (!bad) request(g0);
+    while (w < W && !bad && at < end) {
+        const uint64_t b0 = g0 + (at - g0) / B * B;
+        if (pre_b0 != b0) request(b0);  // a hop longer than a block skipped the requested one
+#pragma unroll
+        for (int j = 0; j < NV; ++j) *reinterpret_cast<uint4 *>(blk + (uint32_t)(j * 64 + lane) * 4u) = pre[j];
+        wave_sync();
+        if (b0 + B < end) request(b0 + B);
+        const uint32_t blk_len = (end - b0 < B) ? (uint32_t)(end - b0) : B;
+        const uint32_t end_rel = (end - b0 < 0xffffffffull) ? (uint32_t)(end - b0) : 0xffffffffu;
+        uint32_t rel = (uint32_t)(at - b0);
+        while (w < W && rel < blk_len && !bad) {
+            // chase up to kWalkHopCap hops inside the block; every value here is wave uniform (SGPRs)
+            const uint32_t w0 = w;
+            uint32_t hops = 0;
+            while (w < W && rel < blk_len && hops < kWalkHopCap) {
+                const uint32_t n = __builtin_amdgcn_readfirstlane(blk[rel]);
+                const uint32_t lim = (w + 1 == W) ? max_last : max_full;
+                if (n > lim || rel + 1u + n > end_rel) { bad = true; break; }
+                hop[hops] = make_uint2(rel, n);
+                rel += n + 1u;
+                ++w;
+                ++hops;
+            }
+            wave_sync();
+            for (uint32_t i = lane; i < hops; i += 64) {
+                const uint2 h = hop[i];
+                wave_off[base + w0 + i] = b0 + h.x;
+                wave_words[base + w0 + i] = h.y;
+            }
+            wave_sync();
+        }
+        at = b0 + rel;
+    }
+    if (w < W) bad = true;
+    if (!bad && at != end) bad = true;
+    if (bad) {
+        for (uint32_t i = w + lane; i < W; i += 64) { wave_off[base + i] = begin; wave_words[base + i] = 0; }
+        if (lane == 0) atomicOr(&st->err, kErrCorrupt);
+    }
+}
+
 // Straightforward lane-per-waveform decoder: global loads and 2-byte stores.
 // Kept as the simple cross-check of the staged kernel below (decode_impl = 0).
 __global__ __launch_bounds__(64) void k_decode_simple(Geom G, const uint32_t *__restrict__ in,
@@ -1206,10 +1317,11 @@ hipError_t launch_encode(const Geom &G, const int16_t *d_in, uint32_t *d_out, ui
 hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                          const uint64_t *d_chunk_word_off, int16_t *d_out, uint64_t *d_wave_off,
                          uint32_t *d_wave_words, uint64_t *d_granules, DevStatus *d_status, int impl,
+                         const uint32_t *d_short_list, uint32_t n_short, const uint32_t *d_long_list, uint32_t n_long,
                          hipEvent_t *ev, hipStream_t s) {
     if (G.total_waves == 0) return hipSuccess;
     mark(ev, 0, s);
-    const bool fused = impl >= 5 && G.uniform;  // the in-launch walk needs the arithmetic chunk mapping
+    const bool fused = impl >= 5 && G.uniform && G.u_wave_len > kWalkShortLen;  // the in-launch walk needs the arithmetic chunk mapping
     if (fused) {
         // granules + ticket word, zeroed before every launch (a granule is its own ready flag)
         hipError_t e = hipMemsetAsync(d_granules, 0, (G.total_waves + 2) * sizeof(uint64_t), s);
@@ -1223,8 +1335,20 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
             default: k_decode_lanes<64, 16, 64, 16, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
         }
     } else {
-        k_walk<<<blocks_for(G.n_chunks, 64), 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off,
-                                                         d_wave_words, d_status);
+        // chunks of short waveforms: stream the chunk through LDS; long waveforms: one dependent load per hop
+        if (G.uniform) {
+            if (G.u_wave_len <= kWalkShortLen)
+                k_walk_block<<<(unsigned)G.n_chunks, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, nullptr,
+                                                                 (uint32_t)G.n_chunks, d_wave_off, d_wave_words, d_status);
+            else
+                k_walk<<<blocks_for(G.n_chunks, 64), 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off,
+                                                                 d_wave_words, d_status);
+        } else {
+            if (n_short) k_walk_block<<<n_short, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_short_list, n_short,
+                                                             d_wave_off, d_wave_words, d_status);
+            if (n_long) k_walk_list<<<blocks_for(n_long, 64), 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_long_list,
+                                                                         n_long, d_wave_off, d_wave_words, d_status);
+        }
         mark(ev, 1, s);
         const unsigned nb = blocks_for(G.total_waves, 64);
         switch (impl) {

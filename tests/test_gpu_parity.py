@@ -297,3 +297,23 @@ def test_rice_parameter_optimiser_is_exact(ctx, O):
         assert int(est[k]) == ref_w.size, k
     best = int(np.argmin(est[1:])) + 1
     assert est[best] <= est[3]
+
+
+def test_short_waveform_chunks_walk_through_lds(ctx, O):
+    # many short waveforms per chunk: the header chain is walked inside an LDS block (k_walk_block)
+    rng = np.random.default_rng(8)
+    for L, n_chunks, W in [(512, 3, 700), (100, 2, 5000), (2048, 2, 40), (3, 2, 20000)]:
+        x = rng.normal(0, 10, n_chunks * W * L).astype(np.int16)
+        opts = (8, L)
+        ref_w, ref_off = O.encode_batch(x, W * L, opts)
+        plan = ctx.plan_uniform(n_chunks, W * L, opts)
+        enc = type(plan.encode(dev(ctx, x)))(dev(ctx, ref_w.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), ref_w.size)
+        for impl in (0, 1, 5):
+            ctx.set_option("decode_impl", impl)
+            assert np.array_equal(plan.decode(enc).cpu().numpy(), x), (L, impl)
+        ctx.set_option("decode_impl", 5)
+        bad = ref_w.copy()
+        bad[ref_off[1] + 1] += 1  # corrupt the first length header of chunk 1
+        import deltarice_amd as dr
+        with pytest.raises(dr.DeltaRiceError):
+            plan.decode(dr.EncodedBatch(dev(ctx, bad.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), bad.size))

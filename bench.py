@@ -45,7 +45,7 @@ def parse_args():
     ap.add_argument("--chunk-waves", type=int, default=2000, help="waveforms per HDF5 chunk")
     ap.add_argument("--m", type=int, default=8, help="RiceParameter")
     ap.add_argument("--dist", choices=["gauss", "ar1"], default="gauss")
-    ap.add_argument("--decode-impl", type=int, default=5)
+    ap.add_argument("--decode-impl", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0: skip)")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; "

@@ -748,6 +748,102 @@ __device__ __forceinline__ void walk_chunk(const Geom &G, uint64_t c, const uint
     if (bad) atomicOr(&st->err, kErrCorrupt);
 }
 
+// The same walk for kWalkChains chunks of a uniform batch per wavefront (lanes 0..kWalkChains-1), with the
+// header loads issued as SCALAR loads (s_load_dword through the scalar cache): under the decode's
+// ~3.6 TB/s of vector traffic a dependent vector load takes ~2.9 us per hop (it queues behind the other
+// waves' 64-line gathers in the CU's vector memory pipeline) and the chain becomes the critical path of
+// the fused launch; the scalar path does not share that queue.
+constexpr int kWalkChains = 8;
+
+__device__ __forceinline__ void walk_chunks_scalar(const Geom &G, uint64_t c0, const uint32_t *__restrict__ in,
+                                                   uint64_t in_words, const uint64_t *__restrict__ chunk_word_off,
+                                                   uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
+                                                   uint64_t *__restrict__ granules, DevStatus *st) {
+    const int lane = lane_id();
+    const uint64_t c = c0 + (uint64_t)lane;
+    const bool mine = lane < kWalkChains && c < G.n_chunks;
+    const uint32_t W = G.u_n_waves, L = G.u_wave_len, N = G.u_n_samples;
+    const uint64_t base = c * W;
+    uint64_t begin = 0, end = 0;
+    bool bad = false;
+    if (mine) {
+        begin = chunk_word_off[c];
+        end = chunk_word_off[c + 1];
+        if (end > in_words || begin + 2 > end || end - begin > 0xffffffffull) { bad = true; end = begin; }
+    }
+    if (in_words == 0) {  // nothing to load from (every chunk is bad)
+        if (mine) {
+            for (uint32_t w = 0; w < W; ++w) {
+                wave_off[base + w] = begin;
+                wave_words[base + w] = 0;
+                if (granules) __hip_atomic_store(granules + base + w, kGranValid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            atomicOr(&st->err, kErrCorrupt);
+        }
+        return;
+    }
+    // word `a` of the stream for lanes 0..kWalkChains-1 (a < in_words), one scalar load per chain
+    auto sload = [&](uint64_t a) __attribute__((always_inline)) -> uint32_t {
+        static_assert(kWalkChains == 8, "the asm block below issues eight loads");
+        uint64_t p[kWalkChains];
+#pragma unroll
+        for (int i = 0; i < kWalkChains; ++i) {
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)a, i);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(a >> 32), i);
+            p[i] = (uint64_t)(uintptr_t)(in + (((uint64_t)hi << 32) | lo));
+        }
+        uint32_t v0, v1, v2, v3, v4, v5, v6, v7;
+        // one block: all eight loads in flight before the wait (left to itself the compiler waits after seven)
+        asm volatile(
+            "s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %9, 0x0\n\ts_load_dword %2, %10, 0x0\n\t"
+            "s_load_dword %3, %11, 0x0\n\ts_load_dword %4, %12, 0x0\n\ts_load_dword %5, %13, 0x0\n\t"
+            "s_load_dword %6, %14, 0x0\n\ts_load_dword %7, %15, 0x0\n\ts_waitcnt lgkmcnt(0)"
+            : "=&s"(v0), "=&s"(v1), "=&s"(v2), "=&s"(v3), "=&s"(v4), "=&s"(v5), "=&s"(v6), "=&s"(v7)
+            : "s"(p[0]), "s"(p[1]), "s"(p[2]), "s"(p[3]), "s"(p[4]), "s"(p[5]), "s"(p[6]), "s"(p[7])
+            : "memory");
+        const uint32_t v[kWalkChains] = {v0, v1, v2, v3, v4, v5, v6, v7};
+        uint32_t r = 0;
+#pragma unroll
+        for (int i = 0; i < kWalkChains; ++i) r = (lane == i) ? v[i] : r;
+        return r;
+    };
+    const uint32_t head = sload((mine && !bad) ? begin : 0ull);
+    if (mine && !bad && head != N) bad = true;  // :306 totalNumberPoints
+    uint64_t at = begin + 1;
+    for (uint32_t w = 0; w < W; ++w) {
+        const bool can = mine && !bad && at < end;
+        const uint32_t nn = sload(can ? at : 0ull);
+        uint32_t n = 0;
+        uint64_t here = at;
+        if (can) {
+            n = nn;
+            const uint32_t len = (w + 1 == W) ? (N - w * L) : L;
+            const uint64_t max_words = ((uint64_t)len * 25u + 31u) >> 5;
+            if (n > max_words || at + 1u + n > end) { bad = true; n = 0; }
+            else at += (uint64_t)n + 1u;
+        } else {
+            bad = true;
+            here = begin;
+        }
+        if (mine) {
+            wave_off[base + w] = here;
+            wave_words[base + w] = n;
+            if (granules)
+                __hip_atomic_store(granules + base + w, kGranValid | ((uint64_t)n << 32) | (uint64_t)(uint32_t)(here - begin),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (mine && !bad && at != end) bad = true;
+    if (mine && bad) atomicOr(&st->err, kErrCorrupt);
+}
+
+__global__ __launch_bounds__(64) void k_walk_scalar(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
+                                                    const uint64_t *__restrict__ chunk_word_off,
+                                                    uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
+                                                    DevStatus *st) {
+    walk_chunks_scalar(G, (uint64_t)blockIdx.x * kWalkChains, in, in_words, chunk_word_off, wave_off, wave_words, nullptr, st);
+}
+
 __global__ __launch_bounds__(64) void k_walk(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
                                              const uint64_t *__restrict__ chunk_word_off,
                                              uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
@@ -948,7 +1044,7 @@ __global__ __launch_bounds__(64) void k_decode_simple(Geom G, const uint32_t *__
 //               so the ~1.7 ms of dependent-load latency of the walk disappears behind the decode.
 //               A ticket holder is by construction running, so waiting on a lower ticket's walker
 //               cannot deadlock whatever the dispatch order.  (Uniform batches only.)
-template <int RW, int LW, int T, int GS, bool FUSED>
+template <int RW, int LW, int T, int GS, bool FUSED, bool PAIR = false, bool CAP2 = false>
 __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
                                                      const uint64_t *__restrict__ chunk_word_off,
                                                      uint64_t *__restrict__ wave_off,
@@ -964,7 +1060,10 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
     constexpr uint32_t WMASK = (1u << 27) - 1u;
     constexpr uint32_t NEED_AT = GS + 2;                                   // must refill below this many words
     static_assert(T % GS == 0 && RW - LW >= GS + 2, "round length / ring slack");
-    __shared__ uint32_t ring[(RW + 1) * 64];  // row r: word w with RW - (w mod RW) == r; row 0 mirrors row RW
+    // row r: word w with RW - (w mod RW) == r; row 0 mirrors row RW and row -1 mirrors row RW - 1 (PAIR reads
+    // three consecutive words: rows r + 1, r, r - 1)
+    __shared__ uint32_t ring_all[(RW + 2) * 64];
+    uint32_t *const ring = ring_all + 64;
     __shared__ __attribute__((aligned(16))) uint32_t obuf[64 * OSW];  // doubles as the start-up tables
     uint64_t *tab_off = reinterpret_cast<uint64_t *>(obuf);  // [64] sample offset of step 0 of round 0
     uint32_t *tab_lo = obuf + 128, *tab_hi = obuf + 192;      // [64] each
@@ -972,6 +1071,7 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
 
     const int lane = lane_id();
     const uint32_t k = G.k;
+    if (CAP2) asm volatile("v_mov_b32 v200, 0" ::: "v200");  // experiment: > 170 VGPRs = at most two waves per SIMD
     // Stores go through pointers with an explicit global address space: once `out` has travelled through
     // nested by-reference lambda captures the compiler no longer infers it and emits flat_store, which
     // also ticks lgkmcnt and serialises against the LDS traffic of the write-out (measured: 2x slower).
@@ -987,11 +1087,16 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
         uint32_t tk = 0;
         if (lane == 0) tk = atomicAdd(ticket, 1u);
         tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
-        const uint32_t n_walk = (uint32_t)((G.n_chunks + 63u) >> 6);
+        const uint32_t n_walk = (G.dbg & 8u) ? (uint32_t)((G.n_chunks + 63u) >> 6)
+                                             : (uint32_t)((G.n_chunks + (uint32_t)kWalkChains - 1u) / (uint32_t)kWalkChains);
         if (tk < n_walk) {  // walker role
             __builtin_amdgcn_s_setprio(3);  // the chain is the critical path of the whole launch (A/B: -2.5 %)
-            const uint64_t c = (uint64_t)tk * 64u + lane;
-            if (c < G.n_chunks) walk_chunk(G, c, in, in_words, chunk_word_off, wave_off, wave_words, granules, st);
+            if (G.dbg & 8u) {  // vector-load walk, 64 chunks per wave (kept for A/B)
+                const uint64_t c = (uint64_t)tk * 64u + lane;
+                if (c < G.n_chunks) walk_chunk(G, c, in, in_words, chunk_word_off, wave_off, wave_words, granules, st);
+            } else {
+                walk_chunks_scalar(G, (uint64_t)tk * kWalkChains, in, in_words, chunk_word_off, wave_off, wave_words, granules, st);
+            }
             return;
         }
         const uint64_t t2 = tk - n_walk;                 // decode ticket, group-major
@@ -1083,7 +1188,10 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
             dst[-(4 * j + 0) * 64] = v[j].x; dst[-(4 * j + 1) * 64] = v[j].y;
             dst[-(4 * j + 2) * 64] = v[j].z; dst[-(4 * j + 3) * 64] = v[j].w;
         }
-        if (r0 == (uint32_t)RW) myring[0] = v[0].x;
+        if (r0 == (uint32_t)RW) {
+            myring[0] = v[0].x;
+            if (PAIR) myring[-64] = v[0].y;
+        }
         flw += (uint32_t)LW;
     };
 
@@ -1127,6 +1235,35 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
 
     auto decode_group = [&](auto first_tag, int tg) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_tag)::value;
+        if (PAIR && !FIRST) {
+            // two samples per ring access: a 64-bit window (three words) always holds two codes (2 x 25 bits),
+            // so the second sample's window is one v_alignbit away from the first one's length -- one LDS
+            // round trip on the dependent chain per two samples instead of one per sample
+#pragma unroll
+            for (int u = 0; u < GS; u += 2) {
+                const uint32_t row = __builtin_amdgcn_ubfe(Q, 5u, (uint32_t)LOG_RW);
+                const uint32_t *wp = myring + row * 64u;
+                const uint32_t lo = wp[0], hi = wp[64], lo2 = wp[-64];
+                const uint32_t winA = __builtin_amdgcn_alignbit(hi, lo, Q);
+                const uint32_t winB = __builtin_amdgcn_alignbit(lo, lo2, Q);
+                const uint32_t q1 = (uint32_t)__builtin_clz(winA);
+                const uint32_t kk1 = (winA < (1u << 24)) ? 16u : k;
+                const uint32_t nu1 = ~(q1 + kk1);  // minus the code length
+                const uint32_t win2 = __builtin_amdgcn_alignbit(winA, winB, nu1);
+                const uint32_t q2 = (uint32_t)__builtin_clz(win2);
+                const uint32_t kk2 = (win2 < (1u << 24)) ? 16u : k;
+                const uint32_t nu2 = ~(q2 + kk2);
+                // v_bfe_u32 and v_alignbit_b32 read 5 bits of their offset / shift: ~t == 31 - t (mod 32) serves both
+                asm("v_add3_u32 %0, %1, %2, %3" : "=v"(Q) : "v"(Q), "v"(nu1), "v"(nu2));
+                const uint32_t z1 = (q1 << kk1) + __builtin_amdgcn_ubfe(winA, nu1, kk1);
+                const uint32_t z2 = (q2 << kk2) + __builtin_amdgcn_ubfe(win2, nu2, kk2);
+                acc += (int32_t)(z1 >> 1) ^ -(int32_t)(z1 & 1u);
+                const uint32_t a1 = (uint32_t)acc & 0xffffu;
+                acc += (int32_t)(z2 >> 1) ^ -(int32_t)(z2 & 1u);
+                *reinterpret_cast<uint32_t *>(myout + tg + u) = a1 | ((uint32_t)acc << 16);
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < GS; ++u) {
             const uint32_t row = __builtin_amdgcn_ubfe(Q, 5u, (uint32_t)LOG_RW);
@@ -1217,6 +1354,7 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
     uint32_t t0 = T;
     for (; t0 < steps && !(t0 >= lo_max && t0 + T <= hi_min); t0 += T) edge_round(t0);
 
+    const uint32_t min_words = (G.dbg & 4u) ? 0u : ((uint32_t)T * (k + 1u)) >> 5;
     uint4 pv0[NV], pv1[NV];               // pieces in flight
     bool pneed0 = false, pneed1 = false;  // this lane has them in flight
     set_limits();
@@ -1224,9 +1362,21 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
 #pragma unroll 1
         for (int tg = 0; tg < T; tg += GS) {
             if (__any((int32_t)(Q - Q_need) <= 0)) {  // one signed compare per test (positions are mod 2^32)
-                if (pneed0) store_piece(pv0);
-                if (pneed1) store_piece(pv1);
-                pneed0 = pneed1 = false;
+                // a piece in flight was requested counting on the words this round consumes at least
+                // (min_words): before the round is over it may only be committed where it already fits
+                uint32_t avail = (flw - ((~Q) >> 5)) & WMASK;
+                if (pneed0 && avail <= (uint32_t)(RW - LW)) {
+                    store_piece(pv0);
+                    pneed0 = false;
+                    avail += (uint32_t)LW;
+                    if (pneed1 && avail <= (uint32_t)(RW - LW)) { store_piece(pv1); pneed1 = false; }
+                }
+                if (!pneed0 && pneed1) {
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) pv0[j] = pv1[j];
+                    pneed0 = true;
+                    pneed1 = false;
+                }
                 wave_sync();
                 sync_refill();
                 set_limits();
@@ -1239,9 +1389,12 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
         wave_sync();
         set_limits();
         {
+            // a piece is committed one interior round after its request: by then every lane has decoded T more
+            // samples of at least k + 1 bits each, i.e. consumed min_words more words
+            const uint32_t mc = (t0 + 2u * T <= hi_min && t0 + T < steps) ? min_words : 0u;
             const uint32_t avail = (flw - ((~Q) >> 5)) & WMASK;
-            pneed0 = (flw < endw) && avail <= (uint32_t)(RW - LW) && !(G.dbg & 2u);
-            pneed1 = pneed0 && (flw + (uint32_t)LW < endw) && avail + (uint32_t)LW <= (uint32_t)(RW - LW);
+            pneed0 = (flw < endw) && avail + (uint32_t)LW <= (uint32_t)RW + mc && !(G.dbg & 2u);
+            pneed1 = pneed0 && (flw + (uint32_t)LW < endw) && avail + 2u * (uint32_t)LW <= (uint32_t)RW + mc;
             if (pneed0) load_piece(pv0);
             if (pneed1) load_piece(pv1, (uint32_t)LW);
         }
@@ -1321,16 +1474,17 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                          hipEvent_t *ev, hipStream_t s) {
     if (G.total_waves == 0) return hipSuccess;
     mark(ev, 0, s);
-    const bool fused = impl >= 5 && G.uniform && G.u_wave_len > kWalkShortLen;  // the in-launch walk needs the arithmetic chunk mapping
+    const bool fused = (impl == 5 || impl == 6 || impl == 8) && G.uniform && G.u_wave_len > kWalkShortLen;  // the in-launch walk needs the arithmetic chunk mapping
     if (fused) {
         // granules + ticket word, zeroed before every launch (a granule is its own ready flag)
         hipError_t e = hipMemsetAsync(d_granules, 0, (G.total_waves + 2) * sizeof(uint64_t), s);
         if (e != hipSuccess) return e;
         mark(ev, 1, s);
         uint32_t *ticket = reinterpret_cast<uint32_t *>(d_granules + G.total_waves);
-        const unsigned n_walk = blocks_for(G.n_chunks, 64);
+        const unsigned n_walk = blocks_for(G.n_chunks, (G.dbg & 8u) ? 64 : kWalkChains);
         const unsigned nb = n_walk + (unsigned)(G.n_chunks * ((G.u_n_waves + 63u) / 64u));
         switch (impl) {
+            case 8: k_decode_lanes<64, 16, 64, 16, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
             case 6: k_decode_lanes<32, 16, 64, 8, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
             default: k_decode_lanes<64, 16, 64, 16, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
         }
@@ -1340,9 +1494,12 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
             if (G.u_wave_len <= kWalkShortLen)
                 k_walk_block<<<(unsigned)G.n_chunks, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, nullptr,
                                                                  (uint32_t)G.n_chunks, d_wave_off, d_wave_words, d_status);
-            else
+            else if (G.dbg & 8u)
                 k_walk<<<blocks_for(G.n_chunks, 64), 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off,
                                                                  d_wave_words, d_status);
+            else
+                k_walk_scalar<<<blocks_for(G.n_chunks, kWalkChains), 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off,
+                                                                                 d_wave_off, d_wave_words, d_status);
         } else {
             if (n_short) k_walk_block<<<n_short, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_short_list, n_short,
                                                              d_wave_off, d_wave_words, d_status);
@@ -1353,6 +1510,12 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
         const unsigned nb = blocks_for(G.total_waves, 64);
         switch (impl) {
             case 0: k_decode_simple<<<nb, 64, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_out); break;
+            case 12: k_decode_lanes<32, 16, 64, 8, false, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
+            case 13: k_decode_lanes<64, 16, 64, 16, false, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
+            case 9: k_decode_lanes<32, 16, 32, 8, false, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
+            case 10: k_decode_lanes<64, 16, 32, 16, false, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
+            case 11: k_decode_lanes<32, 16, 64, 8, false, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
+            case 7: k_decode_lanes<64, 16, 64, 16, false, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
             case 2: k_decode_lanes<32, 16, 64, 8, false><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
             case 3: k_decode_lanes<32, 8, 64, 8, false><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
             case 4: k_decode_lanes<128, 16, 64, 16, false><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;

@@ -43,7 +43,7 @@ def gpu_encode(ctx, plan, x):
     return enc, w, off
 
 
-IMPLS = [0, 1, 2, 3, 4, 5, 6]
+IMPLS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11]
 
 
 # --------------------------------------------------------------------------- golden
@@ -59,7 +59,7 @@ def test_golden_batch_api(ctx, O, golden, name):
         ctx.set_option("decode_impl", impl)
         y = plan.decode(enc).cpu().numpy()
         assert np.array_equal(y, x), f"GPU decode (impl {impl}) differs"
-    ctx.set_option("decode_impl", 5)
+    ctx.set_option("decode_impl", 8)
 
 
 @pytest.mark.parametrize("name", ["kat_docs", "config1_one_chunk", "leftover_20877", "uniform_default",
@@ -138,7 +138,7 @@ def test_random_vs_oracle(ctx, O, n_chunks, chunk_samples, L, k, kind):
         ctx.set_option("decode_impl", impl)
         y = plan.decode(enc).cpu().numpy()
         assert np.array_equal(y, x), f"impl {impl}"
-    ctx.set_option("decode_impl", 5)
+    ctx.set_option("decode_impl", 8)
     # cross direction: oracle-encoded stream decoded on the GPU
     enc2 = type(enc)(dev(ctx, ref_w.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), ref_w.size)
     assert np.array_equal(plan.decode(enc2).cpu().numpy(), x)
@@ -165,7 +165,7 @@ def test_ragged_mixed_waveform_lengths(ctx, O):
     for impl in IMPLS:
         ctx.set_option("decode_impl", impl)
         assert np.array_equal(plan.decode(enc).cpu().numpy(), x)
-    ctx.set_option("decode_impl", 5)
+    ctx.set_option("decode_impl", 8)
 
 
 def test_decode_chunks_in_arbitrary_order(ctx, O):
@@ -215,7 +215,7 @@ def test_corrupt_stream_is_rejected_not_crashed(ctx, O):
             with pytest.raises(dr.DeltaRiceError) as e:
                 plan.decode(enc)
             assert e.value.status == 4
-    ctx.set_option("decode_impl", 5)
+    ctx.set_option("decode_impl", 8)
     with pytest.raises(dr.DeltaRiceError):
         ctx.filter_chunk(w[:-1], opts, reverse=True)
 
@@ -308,10 +308,10 @@ def test_short_waveform_chunks_walk_through_lds(ctx, O):
         ref_w, ref_off = O.encode_batch(x, W * L, opts)
         plan = ctx.plan_uniform(n_chunks, W * L, opts)
         enc = type(plan.encode(dev(ctx, x)))(dev(ctx, ref_w.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), ref_w.size)
-        for impl in (0, 1, 5):
+        for impl in (0, 1, 5, 7, 8):
             ctx.set_option("decode_impl", impl)
             assert np.array_equal(plan.decode(enc).cpu().numpy(), x), (L, impl)
-        ctx.set_option("decode_impl", 5)
+        ctx.set_option("decode_impl", 8)
         bad = ref_w.copy()
         bad[ref_off[1] + 1] += 1  # corrupt the first length header of chunk 1
         import deltarice_amd as dr

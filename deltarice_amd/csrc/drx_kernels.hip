@@ -488,6 +488,46 @@ __device__ __forceinline__ void emit_tile(const PackedCodes &c, uint32_t pb) {
     }
 }
 
+// The same for a full tile, with fewer LDS operations: the lane first concatenates its 8 codes in
+// registers (a right-aligned 128-bit string w3:w2:w1:w0, one funnel shift per word and code), then ORs
+// whole words.  pe = 8 * (LDS byte address of the buffer's word 0) + bit position of the END of the lane's
+// last code; lane_bits <= 128 (the caller checks; 8 codes are 52 bits on the headline data and can
+// only pass 128 with three escapes or more).  Every code is at least one bit long (full tile), so
+// 32 - n is a valid funnel shift.  Words before the lane's first one receive an OR with zero: the
+// buffers carry a 4-word pad in front for that.
+__device__ __forceinline__ void emit_tile_concat(const PackedCodes &c, uint32_t pe) {
+    typedef uint32_t __attribute__((address_space(3))) lds_u32;
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        // v_alignbit_b32 / v_lshl_or_b32 read 5 bits of the shift: for the low half the packed register serves as is
+        const uint32_t nbj = c.nb[j >> 1], rj = c.r[j >> 1], kkj = c.kk[j >> 1];
+        const uint32_t n = (j & 1) ? (nbj >> 16) : nbj;
+        const uint32_t r = (j & 1) ? (rj >> 16) : (rj & 0xffffu);
+        const uint32_t kk = (j & 1) ? (kkj >> 16) : kkj;
+        const uint32_t code32 = (1u << (kk & 31u)) | r;
+        const uint32_t s = 0u - n;  // == 32 - n (mod 32)
+        if (j >= 3) w3 = __builtin_amdgcn_alignbit(w3, w2, s);
+        if (j >= 2) w2 = __builtin_amdgcn_alignbit(w2, w1, s);
+        if (j >= 1) w1 = __builtin_amdgcn_alignbit(w1, w0, s);
+        w0 = (w0 << (n & 31u)) | code32;
+    }
+    // B << (32 - e) == (B << 32) >> e with e = pe & 31: x0 is the word that holds bit pe
+    const uint32_t x0 = __builtin_amdgcn_alignbit(w0, 0u, pe);
+    const uint32_t x1 = __builtin_amdgcn_alignbit(w1, w0, pe);
+    const uint32_t x2 = __builtin_amdgcn_alignbit(w2, w1, pe);
+    const uint32_t x3 = __builtin_amdgcn_alignbit(w3, w2, pe);
+    const uint32_t x4 = __builtin_amdgcn_alignbit(0u, w3, pe);
+    lds_u32 *w = (lds_u32 *)(uintptr_t)(((pe >> 3) & ~3u) - 16u);  // word of x4: positive DS offsets from here
+    __hip_atomic_fetch_or(w + 4, x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_or(w + 3, x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_or(w + 2, x2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (x3 | x4) {
+        __hip_atomic_fetch_or(w + 1, x3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (x4) __hip_atomic_fetch_or(w, x4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
 __device__ __forceinline__ uint32_t lds_addr(const uint32_t *p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t *)p;
 }
@@ -500,12 +540,14 @@ __global__ __launch_bounds__(64 * kEncWaves) void k_encode_fused(Geom G, const i
                                                       uint32_t *__restrict__ wave_words,
                                                       uint64_t *__restrict__ scan_state,
                                                       uint32_t *__restrict__ ticket, DevStatus *st) {
+    // per waveform: 4 pad words (emit_tile_concat ORs zeros below a lane's first word), the code, 4 slack words
     __shared__ __attribute__((aligned(16))) uint32_t buf_all[kEncWaves][kEncCapWords + 8];
     __shared__ uint32_t s_ticket;
     __shared__ uint64_t s_mine[kEncWaves];
     __shared__ uint64_t s_excl;
     const int lane = lane_id();
-    uint32_t *buf = buf_all[threadIdx.x >> 6];
+    uint32_t *row = buf_all[threadIdx.x >> 6];
+    uint32_t *buf = row + 4;
     const uint32_t buf_bits = lds_addr(buf) * 8u;  // LDS is 160 KB: bit addresses fit easily
 
     // Waveform indices by ticket: every lower index is already owned by a running (or finished)
@@ -517,7 +559,7 @@ __global__ __launch_bounds__(64 * kEncWaves) void k_encode_fused(Geom G, const i
     const uint64_t g = (uint64_t)s_ticket * kEncWaves + (threadIdx.x >> 6);
     const bool live = g < G.total_waves;  // the last workgroup may be partial; its idle waves still join the barriers
 
-    for (int i = lane; i < (int)(kEncCapWords + 8) / 4; i += 64) reinterpret_cast<uint4 *>(buf)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = lane; i < (int)(kEncCapWords + 8) / 4; i += 64) reinterpret_cast<uint4 *>(row)[i] = make_uint4(0, 0, 0, 0);
     WaveRef r = locate(G, live ? g : 0);
     if (!live) { r.len = 0; r.idx = 1; }  // an idle wave of the last workgroup: nothing to encode, nothing to add
     const int16_t *x = in + r.sample_off;
@@ -545,13 +587,19 @@ __global__ __launch_bounds__(64 * kEncWaves) void k_encode_fused(Geom G, const i
         const uint32_t incl = wave_incl_scan_dpp(lane_bits);
         const uint32_t tile_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         if (fits && ((P + tile_bits + 31u) >> 5) < (uint64_t)kEncCapWords) {
-            emit_tile<FULLT>(c, buf_bits + (uint32_t)P + incl - lane_bits);
+            if (FULLT && !(G.dbg & 16u) && !__any(lane_bits > 128u))
+                emit_tile_concat(c, buf_bits + (uint32_t)P + incl);
+            else
+                emit_tile<FULLT>(c, buf_bits + (uint32_t)P + incl - lane_bits);
         } else {
             fits = false;
         }
         P += tile_bits;
     };
-    const uint32_t n_full = r.len / kTile;
+    // r.len is the same in every lane (one waveform per wave): say so, or the tile loop is compiled with
+    // per-lane predicates, register copies and a full vmcnt(0) in front of every tile
+    const uint32_t wlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.len);
+    const uint32_t n_full = wlen / kTile;
     {
         // kDepth tiles of loads in flight, in kDepth fixed register sets (the loop is unrolled by
         // kDepth so that no loaded-but-not-yet-arrived register is ever copied): with 4 waves per
@@ -566,23 +614,35 @@ __global__ __launch_bounds__(64 * kEncWaves) void k_encode_fused(Geom G, const i
                 q[u] = make_uint4(0, 0, 0, 0);
                 if ((uint32_t)u < n_full) q[u] = xv[64 * (size_t)u];
             }
+            // while every register set has a successor tile: consume a set, then refill it -- no predicate
+            // on the load, so no copy of a set and a plain vmcnt(kDepth - 1) in front of each tile
+#pragma unroll 1
+            for (; t + 2u * kDepth <= n_full; t += kDepth) {
+#pragma unroll
+                for (int u = 0; u < kDepth; ++u) {
+                    const uint32_t w[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+                    process_tile(w, 8, std::true_type{});
+                    q[u] = xv[64 * (size_t)(t + u + kDepth)];
+                }
+            }
+            // drain: the last kDepth..2 kDepth - 1 full tiles
 #pragma unroll 1
             for (; t < n_full; t += kDepth) {
 #pragma unroll
                 for (int u = 0; u < kDepth; ++u) {
                     if (t + (uint32_t)u < n_full) {
                         const uint32_t w[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
-                        if (t + (uint32_t)u + kDepth < n_full) q[u] = xv[64 * (size_t)(t + u + kDepth)];
                         process_tile(w, 8, std::true_type{});
+                        if (t + (uint32_t)u + kDepth < n_full) q[u] = xv[64 * (size_t)(t + u + kDepth)];
                     }
                 }
             }
             t = n_full;
         }
         // unaligned waveforms, and the trailing partial tile
-        for (uint32_t t0 = t * kTile; t0 < r.len; t0 += kTile) {
+        for (uint32_t t0 = t * kTile; t0 < wlen; t0 += kTile) {
             uint32_t w[4];
-            const int nv = load8_dwords(x, r.len, t0, lane, vec_ok, w);
+            const int nv = load8_dwords(x, wlen, t0, lane, vec_ok, w);
             process_tile(w, nv, std::false_type{});
         }
     }
@@ -671,7 +731,7 @@ __global__ __launch_bounds__(64 * kEncWaves) void k_encode_fused(Geom G, const i
     }
 
     // ---- the code did not fit the LDS buffer: stream it tile by tile to its final position ----
-    for (int i = lane; i < (int)(kEncCapWords + 8) / 4; i += 64) reinterpret_cast<uint4 *>(buf)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = lane; i < (int)(kEncCapWords + 8) / 4; i += 64) reinterpret_cast<uint4 *>(row)[i] = make_uint4(0, 0, 0, 0);
     wave_sync();
     P = 0;
     carry = 0;
@@ -1474,7 +1534,7 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                          hipEvent_t *ev, hipStream_t s) {
     if (G.total_waves == 0) return hipSuccess;
     mark(ev, 0, s);
-    const bool fused = (impl == 5 || impl == 6 || impl == 8) && G.uniform && G.u_wave_len > kWalkShortLen;  // the in-launch walk needs the arithmetic chunk mapping
+    const bool fused = (impl == 5 || impl == 6 || impl == 8 || impl == 14) && G.uniform && G.u_wave_len > kWalkShortLen;  // the in-launch walk needs the arithmetic chunk mapping
     if (fused) {
         // granules + ticket word, zeroed before every launch (a granule is its own ready flag)
         hipError_t e = hipMemsetAsync(d_granules, 0, (G.total_waves + 2) * sizeof(uint64_t), s);
@@ -1484,6 +1544,7 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
         const unsigned n_walk = blocks_for(G.n_chunks, (G.dbg & 8u) ? 64 : kWalkChains);
         const unsigned nb = n_walk + (unsigned)(G.n_chunks * ((G.u_n_waves + 63u) / 64u));
         switch (impl) {
+            case 14: k_decode_lanes<32, 16, 64, 8, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
             case 8: k_decode_lanes<64, 16, 64, 16, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
             case 6: k_decode_lanes<32, 16, 64, 8, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
             default: k_decode_lanes<64, 16, 64, 16, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;

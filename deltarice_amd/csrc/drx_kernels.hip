@@ -1096,10 +1096,13 @@ __global__ __launch_bounds__(64) void k_decode_simple(Geom G, const uint32_t *__
 //               128-byte lines (T = 64).  tools/ubench_store.hip: 16-byte stores reach 5.5 TB/s only
 //               when every contiguous run is a whole line; 64-byte aligned runs give 4.2 TB/s and
 //               runs that straddle lines 2.6-3.3 TB/s whatever their length.
+//   PAIR        two samples per ring access: three words = a 64-bit window always hold two codes
+//               (2 x 25 bits); the second sample's window is v_alignbit(winA, winB, -len1).  One LDS
+//               round trip on the dependent chain per two samples.
 //   FUSED       the header-chain walk runs inside the same launch: workgroups take a ticket; the first
-//               ceil(n_chunks/64) tickets walk (one lane per chunk, publishing one granule per
-//               waveform), every later ticket decodes 64 waveforms of one chunk as soon as their
-//               granules appear.  Decode tickets are dealt group-major (waveforms 0-63 of every chunk,
+//               ceil(n_chunks/8) tickets walk (eight chunks per wave through scalar loads,
+//               walk_chunks_scalar(), publishing one granule per waveform), every later ticket decodes
+//               64 waveforms of one chunk as soon as their granules appear.  Decode tickets are dealt group-major (waveforms 0-63 of every chunk,
 //               then 64-127 of every chunk, ...), the order in which the 2000-hop chains release them,
 //               so the ~1.7 ms of dependent-load latency of the walk disappears behind the decode.
 //               A ticket holder is by construction running, so waiting on a lower ticket's walker
@@ -1111,7 +1114,7 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
                                                      uint32_t *__restrict__ wave_words,
                                                      uint64_t *__restrict__ granules, uint32_t *__restrict__ ticket,
                                                      DevStatus *st, int16_t *__restrict__ out) {
-    static_assert(RW >= 2 * LW && (RW == 32 || RW == 64 || RW == 128) && (LW == 8 || LW == 16), "ring");
+    static_assert(RW >= 2 * LW && (RW == 32 || RW == 64 || RW == 128) && (LW == 8 || LW == 16 || LW == 32), "ring");
     constexpr int LOG_RW = RW == 32 ? 5 : (RW == 64 ? 6 : 7);
     constexpr int OSW = T / 2 + 4;  // output row stride in words (16-byte aligned rows)
     constexpr int PPS = T / 8;      // 16-byte pieces per stream per round
@@ -1534,7 +1537,7 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                          hipEvent_t *ev, hipStream_t s) {
     if (G.total_waves == 0) return hipSuccess;
     mark(ev, 0, s);
-    const bool fused = (impl == 5 || impl == 6 || impl == 8 || impl == 14) && G.uniform && G.u_wave_len > kWalkShortLen;  // the in-launch walk needs the arithmetic chunk mapping
+    const bool fused = (impl == 5 || impl == 6 || impl == 8 || impl == 14 || impl == 15) && G.uniform && G.u_wave_len > kWalkShortLen;  // the in-launch walk needs the arithmetic chunk mapping
     if (fused) {
         // granules + ticket word, zeroed before every launch (a granule is its own ready flag)
         hipError_t e = hipMemsetAsync(d_granules, 0, (G.total_waves + 2) * sizeof(uint64_t), s);
@@ -1544,6 +1547,7 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
         const unsigned n_walk = blocks_for(G.n_chunks, (G.dbg & 8u) ? 64 : kWalkChains);
         const unsigned nb = n_walk + (unsigned)(G.n_chunks * ((G.u_n_waves + 63u) / 64u));
         switch (impl) {
+            case 15: k_decode_lanes<64, 32, 64, 16, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
             case 14: k_decode_lanes<32, 16, 64, 8, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
             case 8: k_decode_lanes<64, 16, 64, 16, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
             case 6: k_decode_lanes<32, 16, 64, 8, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
@@ -1573,6 +1577,7 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
             case 0: k_decode_simple<<<nb, 64, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_out); break;
             case 12: k_decode_lanes<32, 16, 64, 8, false, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
             case 13: k_decode_lanes<64, 16, 64, 16, false, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
+            case 16: k_decode_lanes<64, 32, 64, 16, false, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
             case 9: k_decode_lanes<32, 16, 32, 8, false, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
             case 10: k_decode_lanes<64, 16, 32, 16, false, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
             case 11: k_decode_lanes<32, 16, 64, 8, false, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;

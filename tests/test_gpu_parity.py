@@ -43,7 +43,7 @@ def gpu_encode(ctx, plan, x):
     return enc, w, off
 
 
-IMPLS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 14]
+IMPLS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 14, 15, 16]
 
 
 # --------------------------------------------------------------------------- golden

@@ -411,18 +411,26 @@ struct PackedCodes { uint32_t nb[4], r[4], kk[4]; };
 __device__ __forceinline__ void packed_codes(const uint32_t x[4], uint32_t xprev, uint32_t k, PackedCodes &c) {
     const u16x2 kv = splat(k), kp1 = splat(k + 1u), c16k = splat(16u - k);
     const u16x2 mlo = splat((1u << k) - 1u), mdelta = splat(0xffffu - ((1u << k) - 1u));
+    // stage by stage over the four dwords rather than dword by dword: consecutive instructions are then
+    // independent and the packed-math / op_sel hazards need no s_nop (21 per tile before)
+    u16x2 z[4], qc[4], e[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const uint32_t before = __builtin_amdgcn_alignbit(x[j], j ? x[j - 1] : xprev, 16);  // samples 2j-1, 2j
         const i16x2 d = as_i16x2(x[j]) - as_i16x2(before);                                   // :51-63, mod 2^16
-        const u16x2 z = __builtin_bit_cast(u16x2, (i16x2)(d << (int16_t)1)) ^
-                        __builtin_bit_cast(u16x2, (i16x2)(d >> (int16_t)15));                // zig-zag :207-211
-        const u16x2 qc = __builtin_elementwise_min((u16x2)(z >> kv), splat(8u));            // min(q, 8)
-        const u16x2 e = qc >> (uint16_t)3;                                                   // 1 = escape (:215)
-        c.nb[j] = as_u32(e * c16k + (qc + kp1));   // q+1+k, or 8+1+16
-        c.r[j] = as_u32(z & (e * mdelta + mlo));   // z & (M-1), or z
-        c.kk[j] = as_u32(e * c16k + kv);           // k, or 16
+        z[j] = __builtin_bit_cast(u16x2, (i16x2)(d << (int16_t)1)) ^
+               __builtin_bit_cast(u16x2, (i16x2)(d >> (int16_t)15));                         // zig-zag :207-211
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qc[j] = __builtin_elementwise_min((u16x2)(z[j] >> kv), splat(8u));  // min(q, 8)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e[j] = qc[j] >> (uint16_t)3;                                         // 1 = escape (:215)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c.nb[j] = as_u32(e[j] * c16k + (qc[j] + kp1));   // q+1+k, or 8+1+16
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c.r[j] = as_u32(z[j] & (e[j] * mdelta + mlo));   // z & (M-1), or z
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c.kk[j] = as_u32(e[j] * c16k + kv);              // k, or 16
 }
 
 constexpr uint32_t kEncCapWords = 2048;  // LDS words per waveform buffer (8 KB): 9.3 bits/sample at L = 7000
@@ -495,8 +503,7 @@ __device__ __forceinline__ void emit_tile(const PackedCodes &c, uint32_t pb) {
 // only pass 128 with three escapes or more).  Every code is at least one bit long (full tile), so
 // 32 - n is a valid funnel shift.  Words before the lane's first one receive an OR with zero: the
 // buffers carry a 4-word pad in front for that.
-__device__ __forceinline__ void emit_tile_concat(const PackedCodes &c, uint32_t pe) {
-    typedef uint32_t __attribute__((address_space(3))) lds_u32;
+__device__ __forceinline__ void concat_codes(const PackedCodes &c, uint32_t (&w)[4]) {
     uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -512,12 +519,17 @@ __device__ __forceinline__ void emit_tile_concat(const PackedCodes &c, uint32_t 
         if (j >= 1) w1 = __builtin_amdgcn_alignbit(w1, w0, s);
         w0 = (w0 << (n & 31u)) | code32;
     }
+    w[0] = w0; w[1] = w1; w[2] = w2; w[3] = w3;
+}
+
+__device__ __forceinline__ void place_words(const uint32_t (&wd)[4], uint32_t pe) {
+    typedef uint32_t __attribute__((address_space(3))) lds_u32;
     // B << (32 - e) == (B << 32) >> e with e = pe & 31: x0 is the word that holds bit pe
-    const uint32_t x0 = __builtin_amdgcn_alignbit(w0, 0u, pe);
-    const uint32_t x1 = __builtin_amdgcn_alignbit(w1, w0, pe);
-    const uint32_t x2 = __builtin_amdgcn_alignbit(w2, w1, pe);
-    const uint32_t x3 = __builtin_amdgcn_alignbit(w3, w2, pe);
-    const uint32_t x4 = __builtin_amdgcn_alignbit(0u, w3, pe);
+    const uint32_t x0 = __builtin_amdgcn_alignbit(wd[0], 0u, pe);
+    const uint32_t x1 = __builtin_amdgcn_alignbit(wd[1], wd[0], pe);
+    const uint32_t x2 = __builtin_amdgcn_alignbit(wd[2], wd[1], pe);
+    const uint32_t x3 = __builtin_amdgcn_alignbit(wd[3], wd[2], pe);
+    const uint32_t x4 = __builtin_amdgcn_alignbit(0u, wd[3], pe);
     lds_u32 *w = (lds_u32 *)(uintptr_t)(((pe >> 3) & ~3u) - 16u);  // word of x4: positive DS offsets from here
     __hip_atomic_fetch_or(w + 4, x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __hip_atomic_fetch_or(w + 3, x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -584,11 +596,14 @@ __global__ __launch_bounds__(64 * kEncWaves) void k_encode_fused(Geom G, const i
         packed_codes(w, xprev, k, c);
         if (!FULLT) mask_tail(c, nv);
         const uint32_t lane_bits = lane_tile_bits(c);
+        uint32_t cw[4];
+        if (FULLT) concat_codes(c, cw);  // independent of the scan: fills its DPP wait states
         const uint32_t incl = wave_incl_scan_dpp(lane_bits);
         const uint32_t tile_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        if (fits && ((P + tile_bits + 31u) >> 5) < (uint64_t)kEncCapWords) {
+        if (G.dbg & 32u) {  // ablation: no emission
+        } else if (fits && ((P + tile_bits + 31u) >> 5) < (uint64_t)kEncCapWords) {
             if (FULLT && !(G.dbg & 16u) && !__any(lane_bits > 128u))
-                emit_tile_concat(c, buf_bits + (uint32_t)P + incl);
+                place_words(cw, buf_bits + (uint32_t)P + incl);
             else
                 emit_tile<FULLT>(c, buf_bits + (uint32_t)P + incl - lane_bits);
         } else {
@@ -666,8 +681,9 @@ __global__ __launch_bounds__(64 * kEncWaves) void k_encode_fused(Geom G, const i
         for (int i = 0; i < kEncWaves; ++i) block_sum += s_mine[i];
         const uint64_t T = s_ticket;
         uint64_t excl_blk = 0;
-        if (T == 0) {
-            if (lane == 0) __hip_atomic_store(scan_state, kScanPrefix | block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (T == 0 || (G.dbg & 128u)) {  // dbg 128: ablation, no look-back (positions are wrong)
+            if (lane == 0) __hip_atomic_store(scan_state + T, kScanPrefix | block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (T) excl_blk = T * 2048ull * kEncWaves;
         } else {
             if (lane == 0) __hip_atomic_store(scan_state + T, kScanAgg | block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int64_t base = (int64_t)T - 1;
@@ -726,7 +742,8 @@ __global__ __launch_bounds__(64 * kEncWaves) void k_encode_fused(Geom G, const i
     }
     uint32_t *__restrict__ outp = out + pos + 1;
     if (fits) {
-        for (uint32_t i = lane; i < n; i += 64) outp[i] = buf[i];
+        if (!(G.dbg & 64u))
+            for (uint32_t i = lane; i < n; i += 64) outp[i] = buf[i];
         return;
     }
 

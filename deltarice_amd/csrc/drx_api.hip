@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <string>
@@ -367,20 +368,46 @@ drx_status drx_encode(drx_plan *p, const int16_t *d_in, uint32_t *d_out, uint64_
     return DRX_OK;
 }
 
-drx_status drx_decode(drx_plan *p, const uint32_t *d_in, uint64_t in_words,
-                      const uint64_t *d_chunk_word_off, int16_t *d_out) {
+static drx_status decode_launch(drx_plan *p, const uint32_t *d_in, uint64_t in_words,
+                                const uint64_t *d_chunk_word_off, int16_t *d_out, bool tables_ready) {
     if (!p || !d_in || !d_chunk_word_off || !d_out) return DRX_ERR_ARG;
     drx_ctx *ctx = p->ctx;
     DRX_HIP(ctx, hipSetDevice(ctx->device));
     DRX_HIP(ctx, hipMemsetAsync(p->d_status, 0, sizeof(DevStatus), ctx->stream));
     p->G.dbg = ctx->debug_flags;
     DRX_HIP(ctx, launch_decode(p->G, d_in, in_words, d_chunk_word_off, d_out, p->d_wave_off,
-                               p->d_wave_words, p->d_scan, p->d_status, p->G.n_taps ? 0 : ctx->decode_impl,
+                               p->d_wave_words, p->d_scan, p->d_status,
+                               (tables_ready ? 100 : 0) + (p->G.n_taps ? 0 : ctx->decode_impl),
                                p->d_walk_lists, p->n_short, p->d_walk_lists ? p->d_walk_lists + p->n_short : nullptr,
                                p->n_long, ctx->profile ? p->ev : nullptr, ctx->stream));
     p->ev_valid = ctx->profile != 0;
     p->last_was_encode = false;
     return DRX_OK;
+}
+
+drx_status drx_decode(drx_plan *p, const uint32_t *d_in, uint64_t in_words,
+                      const uint64_t *d_chunk_word_off, int16_t *d_out) {
+    return decode_launch(p, d_in, in_words, d_chunk_word_off, d_out, false);
+}
+
+// Header chain of ONE encoded chunk in host memory (src/deltaRice.c:320-325), with the validation the device
+// walk does: sample count, every n_i within 25 bits per sample, the chain ends exactly at the chunk end.
+static bool walk_chunk_host(const uint32_t *w, uint64_t n_words, uint32_t n_samples, uint32_t wave_len,
+                            uint64_t *wave_off, uint32_t *wave_words) {
+    if (n_words < 2 || w[0] != n_samples) return false;
+    const uint32_t L = wave_len ? wave_len : n_samples;
+    const uint64_t W = ((uint64_t)n_samples + L - 1) / L;
+    uint64_t at = 1;
+    for (uint64_t i = 0; i < W; ++i) {
+        if (at >= n_words) return false;
+        const uint32_t n = w[at];
+        const uint64_t len = (i + 1 == W) ? (uint64_t)n_samples - i * L : L;
+        if (n > ((len * 25u + 31u) >> 5) || at + 1u + n > n_words) return false;
+        wave_off[i] = at;
+        wave_words[i] = n;
+        at += (uint64_t)n + 1u;
+    }
+    return at == n_words;
 }
 
 drx_status drx_estimate_words(drx_plan *p, const int16_t *d_in, uint64_t words_out[16]) {
@@ -466,6 +493,16 @@ drx_status drx_filter_chunk_host(drx_ctx *ctx, int reverse, size_t cd_nelmts, co
         memcpy(ctx->hp_taps, o.taps, sizeof ctx->hp_taps);
     }
     drx_plan *plan = ctx->host_plan;
+    // DRX_TRACE=1: wall time of each phase of the call on stderr
+    static const bool trace = getenv("DRX_TRACE") != nullptr;
+    auto now = []() { return std::chrono::steady_clock::now(); };
+    auto t_prev = now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        const auto t = now();
+        fprintf(stderr, "[drx] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
     const size_t raw_bytes = (size_t)n_samples * 2;
     const size_t enc_cap_bytes = (size_t)plan->max_words * 4;
     void *result = nullptr;
@@ -476,28 +513,52 @@ drx_status drx_filter_chunk_host(drx_ctx *ctx, int reverse, size_t cd_nelmts, co
         if (!reverse) {
             e = hipMemcpyAsync(ctx->d_raw, in, raw_bytes, hipMemcpyHostToDevice, ctx->stream);
             if (e != hipSuccess) { st = fail(ctx, DRX_ERR_DEVICE, "H2D failed: %s", hipGetErrorString(e)); break; }
+            lap("encode: H2D issue");
             if ((st = drx_encode(plan, (const int16_t *)ctx->d_raw, (uint32_t *)ctx->d_enc, plan->max_words, ctx->d_off)) != DRX_OK) break;
             uint64_t words = 0;
             if ((st = drx_plan_finish(plan, &words)) != DRX_OK) break;
+            lap("encode: kernels + finish");
             const size_t nb = (size_t)words * 4;
             result = malloc(nb);
             if (!result) { st = DRX_ERR_NOMEM; break; }
             e = hipMemcpyAsync(result, ctx->d_enc, nb, hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            lap("encode: D2H");
             if (e != hipSuccess) { st = fail(ctx, DRX_ERR_DEVICE, "D2H failed: %s", hipGetErrorString(e)); break; }
             *out_bytes = nb;
         } else {
-            const uint64_t off[2] = {0, (uint64_t)(nbytes / 4)};
+            // the chunk goes to the device while the CPU walks its header chain: 2000 dependent loads are
+            // 1.7 ms of HBM round trips on the GPU and ~0.1 ms out of host memory
+            const uint64_t W = plan->G.total_waves;
+            const size_t tab_bytes = 16 + (size_t)W * (sizeof(uint64_t) + sizeof(uint32_t));
+            if ((st = grow(ctx, &ctx->h_pin, &ctx->pin_cap, tab_bytes, true)) != DRX_OK) break;
+            uint64_t *h_off = (uint64_t *)ctx->h_pin;              // [2] chunk table, then [W] wave_off
+            uint32_t *h_words = (uint32_t *)(h_off + 2 + W);       // [W] wave_words
+            h_off[0] = 0;
+            h_off[1] = (uint64_t)(nbytes / 4);
             e = hipMemcpyAsync(ctx->d_enc, in, nbytes, hipMemcpyHostToDevice, ctx->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_off, off, sizeof off, hipMemcpyHostToDevice, ctx->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // `off` is a stack temporary
+            lap("decode: H2D chunk");
+            if (!walk_chunk_host((const uint32_t *)in, nbytes / 4, n_samples, L, h_off + 2, h_words)) {
+                (void)hipStreamSynchronize(ctx->stream);
+                st = fail(ctx, DRX_ERR_CORRUPT, "encoded chunk failed header-chain validation");
+                break;
+            }
+            lap("decode: host walk");
+            if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_off, h_off, 2 * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(plan->d_wave_off, h_off + 2, W * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(plan->d_wave_words, h_words, W * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+            lap("decode: H2D tables");
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the pinned table is reused by the next call
             if (e != hipSuccess) { st = fail(ctx, DRX_ERR_DEVICE, "H2D failed: %s", hipGetErrorString(e)); break; }
-            if ((st = drx_decode(plan, (const uint32_t *)ctx->d_enc, nbytes / 4, ctx->d_off, (int16_t *)ctx->d_raw)) != DRX_OK) break;
+            lap("decode: H2D sync");
+            if ((st = decode_launch(plan, (const uint32_t *)ctx->d_enc, nbytes / 4, ctx->d_off, (int16_t *)ctx->d_raw, true)) != DRX_OK) break;
             if ((st = drx_plan_finish(plan, nullptr)) != DRX_OK) break;
+            lap("decode: kernels + finish");
             result = malloc(raw_bytes);
             if (!result) { st = DRX_ERR_NOMEM; break; }
             e = hipMemcpyAsync(result, ctx->d_raw, raw_bytes, hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            lap("decode: D2H");
             if (e != hipSuccess) { st = fail(ctx, DRX_ERR_DEVICE, "D2H failed: %s", hipGetErrorString(e)); break; }
             *out_bytes = raw_bytes;
         }

@@ -1554,6 +1554,12 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                          hipEvent_t *ev, hipStream_t s) {
     if (G.total_waves == 0) return hipSuccess;
     mark(ev, 0, s);
+    // impl >= 100: wave_off / wave_words are already filled in (the one-chunk host path walks the header
+    // chain on the CPU while the chunk is in flight to the device): decode with variant impl - 100, no walk
+    const bool tables_ready = impl >= 100;
+    if (tables_ready) impl -= 100;
+    if (tables_ready && (impl == 5 || impl == 6)) impl = 1;
+    if (tables_ready && (impl == 8 || impl == 14 || impl == 15)) impl = 7;
     const bool fused = (impl == 5 || impl == 6 || impl == 8 || impl == 14 || impl == 15) && G.uniform && G.u_wave_len > kWalkShortLen;  // the in-launch walk needs the arithmetic chunk mapping
     if (fused) {
         // granules + ticket word, zeroed before every launch (a granule is its own ready flag)
@@ -1572,7 +1578,8 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
         }
     } else {
         // chunks of short waveforms: stream the chunk through LDS; long waveforms: one dependent load per hop
-        if (G.uniform) {
+        if (tables_ready) {
+        } else if (G.uniform) {
             if (G.u_wave_len <= kWalkShortLen)
                 k_walk_block<<<(unsigned)G.n_chunks, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, nullptr,
                                                                  (uint32_t)G.n_chunks, d_wave_off, d_wave_words, d_status);

@@ -216,8 +216,13 @@ def test_corrupt_stream_is_rejected_not_crashed(ctx, O):
                 plan.decode(enc)
             assert e.value.status == 4
     ctx.set_option("decode_impl", 8)
-    with pytest.raises(dr.DeltaRiceError):
-        ctx.filter_chunk(w[:-1], opts, reverse=True)
+    # the one-chunk host path walks the header chain on the CPU: same verdicts
+    for bad in (w[:-1], np.concatenate([w[:1] + 1, w[1:]]), np.concatenate([w[:1], w[1:2] + 1, w[2:]]),
+                np.concatenate([w[:1], np.array([0x7FFFFFFF], np.uint32), w[2:]]), np.concatenate([w, w[-1:]])):
+        with pytest.raises(dr.DeltaRiceError) as e:
+            ctx.filter_chunk(bad, opts, reverse=True)
+        assert e.value.status == 4
+    assert np.array_equal(np.frombuffer(ctx.filter_chunk(w, opts, reverse=True), np.int16), x)
 
 
 def test_capacity_error(ctx):

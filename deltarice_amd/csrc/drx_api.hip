@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <chrono>
 #include <mutex>
 #include <new>
@@ -277,6 +278,13 @@ drx_status drx_plan_create(drx_ctx *ctx, uint64_t n_chunks, const uint32_t *chun
         p->n_long = (uint32_t)lists.size() - p->n_short;
         if (e == hipSuccess) e = hipMalloc((void **)&p->d_walk_lists, lists.size() * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMemcpy(p->d_walk_lists, lists.data(), lists.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        uint32_t max_groups = 0;
+        for (uint64_t c = 0; c < n_chunks; ++c) max_groups = std::max(max_groups, (desc[c].n_waves + 63u) / 64u);
+        p->G.walk_short = p->d_walk_lists;
+        p->G.walk_long = p->d_walk_lists ? p->d_walk_lists + p->n_short : nullptr;
+        p->G.n_short = p->n_short;
+        p->G.n_long = p->n_long;
+        p->G.max_groups = max_groups;
         if (e != hipSuccess) st = fail(ctx, DRX_ERR_DEVICE, "chunk table upload failed: %s", hipGetErrorString(e));
     }
     if (st != DRX_OK) { plan_free(p); return st; }

@@ -32,6 +32,10 @@ struct Geom {
     const int32_t *taps;
     uint32_t dbg;  // ablation switches for profiling builds of the decode kernel (0 in normal use):
                    // bit 0: skip the output stores, bit 1: skip the stream loads
+    // ragged batches, walk inside the decode launch: chunk indices, short-waveform chunks first
+    // (walk_short[n_short], then walk_long[n_long]), and the largest ceil(n_waves / 64) of any chunk
+    const uint32_t *walk_short, *walk_long;
+    uint32_t n_short, n_long, max_groups;
 };
 
 struct DevStatus {

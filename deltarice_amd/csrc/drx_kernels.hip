@@ -832,15 +832,23 @@ __device__ __forceinline__ void walk_chunk(const Geom &G, uint64_t c, const uint
 // the fused launch; the scalar path does not share that queue.
 constexpr int kWalkChains = 8;
 
-__device__ __forceinline__ void walk_chunks_scalar(const Geom &G, uint64_t c0, const uint32_t *__restrict__ in,
+__device__ __forceinline__ void walk_chunks_scalar(const Geom &G, uint64_t c0, const uint32_t *__restrict__ list,
+                                                   uint64_t n_list, const uint32_t *__restrict__ in,
                                                    uint64_t in_words, const uint64_t *__restrict__ chunk_word_off,
                                                    uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
                                                    uint64_t *__restrict__ granules, DevStatus *st) {
+    // lanes 0..kWalkChains-1 take entries c0.. of the chunk list (list == nullptr: chunk index = entry)
     const int lane = lane_id();
-    const uint64_t c = c0 + (uint64_t)lane;
-    const bool mine = lane < kWalkChains && c < G.n_chunks;
-    const uint32_t W = G.u_n_waves, L = G.u_wave_len, N = G.u_n_samples;
-    const uint64_t base = c * W;
+    const uint64_t e = c0 + (uint64_t)lane;
+    const bool mine = lane < kWalkChains && e < n_list;
+    const uint64_t c = mine ? (list ? (uint64_t)list[e] : e) : 0;
+    uint32_t W = 0, L = 1, N = 0;
+    uint64_t base = 0;
+    if (mine) {
+        if (G.uniform) { W = G.u_n_waves; L = G.u_wave_len; N = G.u_n_samples; base = c * W; }
+        else { const ChunkDesc d = G.chunks[c]; W = d.n_waves; L = d.wave_len; N = d.n_samples; base = d.wave_base; }
+    }
+    const uint32_t W_max = wave_max_u32(W);
     uint64_t begin = 0, end = 0;
     bool bad = false;
     if (mine) {
@@ -887,8 +895,9 @@ __device__ __forceinline__ void walk_chunks_scalar(const Geom &G, uint64_t c0, c
     const uint32_t head = sload((mine && !bad) ? begin : 0ull);
     if (mine && !bad && head != N) bad = true;  // :306 totalNumberPoints
     uint64_t at = begin + 1;
-    for (uint32_t w = 0; w < W; ++w) {
-        const bool can = mine && !bad && at < end;
+    for (uint32_t w = 0; w < W_max; ++w) {
+        const bool live = mine && w < W;  // chunks of a ragged batch differ in their number of waveforms
+        const bool can = live && !bad && at < end;
         const uint32_t nn = sload(can ? at : 0ull);
         uint32_t n = 0;
         uint64_t here = at;
@@ -898,11 +907,11 @@ __device__ __forceinline__ void walk_chunks_scalar(const Geom &G, uint64_t c0, c
             const uint64_t max_words = ((uint64_t)len * 25u + 31u) >> 5;
             if (n > max_words || at + 1u + n > end) { bad = true; n = 0; }
             else at += (uint64_t)n + 1u;
-        } else {
+        } else if (live) {
             bad = true;
             here = begin;
         }
-        if (mine) {
+        if (live) {
             wave_off[base + w] = here;
             wave_words[base + w] = n;
             if (granules)
@@ -918,7 +927,8 @@ __global__ __launch_bounds__(64) void k_walk_scalar(Geom G, const uint32_t *__re
                                                     const uint64_t *__restrict__ chunk_word_off,
                                                     uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
                                                     DevStatus *st) {
-    walk_chunks_scalar(G, (uint64_t)blockIdx.x * kWalkChains, in, in_words, chunk_word_off, wave_off, wave_words, nullptr, st);
+    walk_chunks_scalar(G, (uint64_t)blockIdx.x * kWalkChains, nullptr, G.n_chunks, in, in_words, chunk_word_off, wave_off,
+                       wave_words, nullptr, st);
 }
 
 __global__ __launch_bounds__(64) void k_walk(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
@@ -950,17 +960,13 @@ constexpr uint32_t kWalkShortLen = 2048;  // WaveformLength up to which a chunk 
 
 constexpr uint32_t kWalkHopCap = 1024;   // hops buffered in LDS between coalesced flushes
 
-__global__ __launch_bounds__(64) void k_walk_block(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
-                                                   const uint64_t *__restrict__ chunk_word_off,
-                                                   const uint32_t *__restrict__ chunk_list, uint32_t n_list,
-                                                   uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
-                                                   DevStatus *st) {
+// blk: kWalkBlockWords words (16-byte aligned), hop: kWalkHopCap entries, both in LDS and private to the wave.
+__device__ __forceinline__ void walk_chunk_block(const Geom &G, uint64_t c, const uint32_t *__restrict__ in,
+                                                 uint64_t in_words, const uint64_t *__restrict__ chunk_word_off,
+                                                 uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
+                                                 uint64_t *__restrict__ granules, DevStatus *st, uint32_t *blk, uint2 *hop) {
     constexpr uint32_t B = kWalkBlockWords;
     constexpr int NV = B / 256;  // 16-byte loads per lane and block
-    __shared__ __attribute__((aligned(16))) uint32_t blk[B];
-    __shared__ __attribute__((aligned(8))) uint2 hop[kWalkHopCap];  // {position in the block, n}
-    if (blockIdx.x >= n_list) return;
-    const uint64_t c = chunk_list ? chunk_list[blockIdx.x] : blockIdx.x;
     const int lane = lane_id();
     uint64_t base;
     uint32_t W, L, N;
@@ -969,7 +975,7 @@ __global__ __launch_bounds__(64) void k_walk_block(Geom G, const uint32_t *__res
     const uint64_t begin = chunk_word_off[c];
     uint64_t end = chunk_word_off[c + 1];
     bool bad = false;
-    if (end > in_words || begin + 2 > end) { bad = true; end = begin; }
+    if (end > in_words || begin + 2 > end || end - begin > 0xffffffffull) { bad = true; end = begin; }
     if (!bad && in[begin] != N) bad = true;
     const uint32_t max_full = (uint32_t)(((uint64_t)L * 25u + 31u) >> 5);
     const uint32_t max_last = W ? (uint32_t)(((uint64_t)(N - (W - 1) * L) * 25u + 31u) >> 5) : 0u;
@@ -1028,6 +1034,10 @@ __global__ __launch_bounds__(64) void k_walk_block(Geom G, const uint32_t *__res
                 const uint2 h = hop[i];
                 wave_off[base + w0 + i] = b0 + h.x;
                 wave_words[base + w0 + i] = h.y;
+                if (granules)
+                    __hip_atomic_store(granules + base + w0 + i,
+                                       kGranValid | ((uint64_t)h.y << 32) | (uint64_t)(uint32_t)(b0 + h.x - begin),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             wave_sync();
         }
@@ -1036,9 +1046,25 @@ __global__ __launch_bounds__(64) void k_walk_block(Geom G, const uint32_t *__res
     if (w < W) bad = true;
     if (!bad && at != end) bad = true;
     if (bad) {
-        for (uint32_t i = w + lane; i < W; i += 64) { wave_off[base + i] = begin; wave_words[base + i] = 0; }
+        for (uint32_t i = w + lane; i < W; i += 64) {
+            wave_off[base + i] = begin;
+            wave_words[base + i] = 0;
+            if (granules) __hip_atomic_store(granules + base + i, kGranValid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (lane == 0) atomicOr(&st->err, kErrCorrupt);
     }
+}
+
+__global__ __launch_bounds__(64) void k_walk_block(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
+                                                   const uint64_t *__restrict__ chunk_word_off,
+                                                   const uint32_t *__restrict__ chunk_list, uint32_t n_list,
+                                                   uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
+                                                   DevStatus *st) {
+    __shared__ __attribute__((aligned(16))) uint32_t blk[kWalkBlockWords];
+    __shared__ __attribute__((aligned(8))) uint2 hop[kWalkHopCap];  // {position in the block, n}
+    if (blockIdx.x >= n_list) return;
+    const uint64_t c = chunk_list ? chunk_list[blockIdx.x] : blockIdx.x;
+    walk_chunk_block(G, c, in, in_words, chunk_word_off, wave_off, wave_words, nullptr, st, blk, hop);
 }
 
 // Straightforward lane-per-waveform decoder: global loads and 2-byte stores.
@@ -1167,27 +1193,54 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
         uint32_t tk = 0;
         if (lane == 0) tk = atomicAdd(ticket, 1u);
         tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+        // walker tickets first.  Chunks of short waveforms (tens of thousands of hops) are streamed
+        // through LDS by a whole wave each (walk_chunk_block, in this wave's ring/transposition LDS),
+        // the others are chased through scalar loads, kWalkChains chunks per wave.
+        constexpr bool kBlockWalkFits = sizeof(ring_all) >= kWalkBlockWords * 4u && sizeof(obuf) >= kWalkHopCap * 8u;
+        const bool u_short = G.uniform && G.u_wave_len <= kWalkShortLen;
+        const uint32_t n_blockwalk = G.uniform ? (u_short ? (uint32_t)G.n_chunks : 0u) : G.n_short;
+        const uint64_t n_chain = G.uniform ? (u_short ? 0ull : G.n_chunks) : (uint64_t)G.n_long;
         const uint32_t n_walk = (G.dbg & 8u) ? (uint32_t)((G.n_chunks + 63u) >> 6)
-                                             : (uint32_t)((G.n_chunks + (uint32_t)kWalkChains - 1u) / (uint32_t)kWalkChains);
+                                             : n_blockwalk + (uint32_t)((n_chain + (uint32_t)kWalkChains - 1u) / (uint32_t)kWalkChains);
         if (tk < n_walk) {  // walker role
             __builtin_amdgcn_s_setprio(3);  // the chain is the critical path of the whole launch (A/B: -2.5 %)
-            if (G.dbg & 8u) {  // vector-load walk, 64 chunks per wave (kept for A/B)
+            if (G.dbg & 8u) {  // vector-load walk, 64 chunks per wave (kept for A/B; uniform batches)
                 const uint64_t c = (uint64_t)tk * 64u + lane;
                 if (c < G.n_chunks) walk_chunk(G, c, in, in_words, chunk_word_off, wave_off, wave_words, granules, st);
+            } else if (tk < n_blockwalk) {
+                if constexpr (kBlockWalkFits) {
+                    const uint64_t c = G.uniform ? (uint64_t)tk : (uint64_t)G.walk_short[tk];
+                    walk_chunk_block(G, c, in, in_words, chunk_word_off, wave_off, wave_words, granules, st, ring_all,
+                                     reinterpret_cast<uint2 *>(obuf));
+                }
             } else {
-                walk_chunks_scalar(G, (uint64_t)tk * kWalkChains, in, in_words, chunk_word_off, wave_off, wave_words, granules, st);
+                walk_chunks_scalar(G, (uint64_t)(tk - n_blockwalk) * kWalkChains, G.uniform ? nullptr : G.walk_long, n_chain,
+                                   in, in_words, chunk_word_off, wave_off, wave_words, granules, st);
             }
             return;
         }
-        const uint64_t t2 = tk - n_walk;                 // decode ticket, group-major
+        // decode tickets, group-major: waveforms 0-63 of every chunk, then 64-127 of every chunk, ...
+        const uint64_t t2 = tk - n_walk;
         const uint64_t grp = t2 / G.n_chunks, c = t2 - grp * G.n_chunks;
         const uint32_t idx = (uint32_t)grp * 64u + lane;  // waveform index inside chunk c
-        active = idx < G.u_n_waves;
-        g = c * G.u_n_waves + idx;
         uint64_t gr = 0;
-        if (active) {
-            len = (idx + 1 == G.u_n_waves) ? (G.u_n_samples - idx * G.u_wave_len) : G.u_wave_len;
-            ooff = c * (uint64_t)G.u_n_samples + (uint64_t)idx * G.u_wave_len;
+        if (G.uniform) {
+            active = idx < G.u_n_waves;
+            g = c * G.u_n_waves + idx;
+            if (active) {
+                len = (idx + 1 == G.u_n_waves) ? (G.u_n_samples - idx * G.u_wave_len) : G.u_wave_len;
+                ooff = c * (uint64_t)G.u_n_samples + (uint64_t)idx * G.u_wave_len;
+            }
+        } else {
+            // ragged: the grid covers max_groups groups of every chunk; a chunk with fewer has idle tickets
+            const ChunkDesc d = G.chunks[c];
+            if ((uint32_t)grp * 64u >= d.n_waves) return;
+            active = idx < d.n_waves;
+            g = d.wave_base + idx;
+            if (active) {
+                len = (idx + 1 == d.n_waves) ? (d.n_samples - idx * d.wave_len) : d.wave_len;
+                ooff = d.sample_off + (uint64_t)idx * d.wave_len;
+            }
         }
         uint32_t spins = 0;
         for (;;) {  // wait for this wave's granules; the walker that writes them holds a lower ticket
@@ -1560,15 +1613,29 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
     if (tables_ready) impl -= 100;
     if (tables_ready && (impl == 5 || impl == 6)) impl = 1;
     if (tables_ready && (impl == 8 || impl == 14 || impl == 15)) impl = 7;
-    const bool fused = (impl == 5 || impl == 6 || impl == 8 || impl == 14 || impl == 15) && G.uniform && G.u_wave_len > kWalkShortLen;  // the in-launch walk needs the arithmetic chunk mapping
+    // the walk runs inside the decode launch; batches that need the LDS block walk (ragged ones, short
+    // waveforms) only with the 64-word ring, whose LDS the walker role borrows
+    const bool big_ring = impl == 8 || impl == 15 || impl == 5;
+    const bool needs_block = !G.uniform || G.u_wave_len <= kWalkShortLen;
+    // ragged: the group-major grid has max_groups tickets per chunk; not when most of them would be idle
+    const bool sparse = !G.uniform && (uint64_t)G.n_chunks * G.max_groups > 8ull * ((G.total_waves + 63u) / 64u) + 4096ull;
+    const bool fused = (impl == 5 || impl == 6 || impl == 8 || impl == 14 || impl == 15) && (!needs_block || big_ring) &&
+                       !((G.dbg & 8u) && needs_block) && !sparse;  // the in-launch walk needs the arithmetic chunk mapping
     if (fused) {
         // granules + ticket word, zeroed before every launch (a granule is its own ready flag)
         hipError_t e = hipMemsetAsync(d_granules, 0, (G.total_waves + 2) * sizeof(uint64_t), s);
         if (e != hipSuccess) return e;
         mark(ev, 1, s);
         uint32_t *ticket = reinterpret_cast<uint32_t *>(d_granules + G.total_waves);
-        const unsigned n_walk = blocks_for(G.n_chunks, (G.dbg & 8u) ? 64 : kWalkChains);
-        const unsigned nb = n_walk + (unsigned)(G.n_chunks * ((G.u_n_waves + 63u) / 64u));
+        unsigned n_walk, groups;
+        if (G.uniform) {
+            n_walk = (G.u_wave_len <= kWalkShortLen) ? (unsigned)G.n_chunks : blocks_for(G.n_chunks, (G.dbg & 8u) ? 64 : kWalkChains);
+            groups = (G.u_n_waves + 63u) / 64u;
+        } else {
+            n_walk = G.n_short + blocks_for(G.n_long, kWalkChains);
+            groups = G.max_groups;
+        }
+        const unsigned nb = n_walk + (unsigned)(G.n_chunks * groups);
         switch (impl) {
             case 15: k_decode_lanes<64, 32, 64, 16, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
             case 14: k_decode_lanes<32, 16, 64, 8, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;

@@ -179,7 +179,7 @@ void *drx_ctx_stream(const drx_ctx *c) { return c ? (void *)c->stream : nullptr;
 drx_status drx_ctx_set_option(drx_ctx *c, const char *key, int64_t value) {
     if (!c || !key) return DRX_ERR_ARG;
     if (!strcmp(key, "decode_impl")) {
-        if (value < 0 || value > 16) return DRX_ERR_ARG;
+        if (value < 0 || value > 17) return DRX_ERR_ARG;
         c->decode_impl = (int)value;
         return DRX_OK;
     }

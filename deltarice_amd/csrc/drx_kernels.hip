@@ -1612,14 +1612,14 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
     const bool tables_ready = impl >= 100;
     if (tables_ready) impl -= 100;
     if (tables_ready && (impl == 5 || impl == 6)) impl = 1;
-    if (tables_ready && (impl == 8 || impl == 14 || impl == 15)) impl = 7;
+    if (tables_ready && (impl == 8 || impl == 14 || impl == 15 || impl == 17)) impl = 7;
     // the walk runs inside the decode launch; batches that need the LDS block walk (ragged ones, short
     // waveforms) only with the 64-word ring, whose LDS the walker role borrows
-    const bool big_ring = impl == 8 || impl == 15 || impl == 5;
+    const bool big_ring = impl == 8 || impl == 15 || impl == 5 || impl == 17;
     const bool needs_block = !G.uniform || G.u_wave_len <= kWalkShortLen;
     // ragged: the group-major grid has max_groups tickets per chunk; not when most of them would be idle
     const bool sparse = !G.uniform && (uint64_t)G.n_chunks * G.max_groups > 8ull * ((G.total_waves + 63u) / 64u) + 4096ull;
-    const bool fused = (impl == 5 || impl == 6 || impl == 8 || impl == 14 || impl == 15) && (!needs_block || big_ring) &&
+    const bool fused = (impl == 5 || impl == 6 || impl == 8 || impl == 14 || impl == 15 || impl == 17) && (!needs_block || big_ring) &&
                        !((G.dbg & 8u) && needs_block) && !sparse;  // the in-launch walk needs the arithmetic chunk mapping
     if (fused) {
         // granules + ticket word, zeroed before every launch (a granule is its own ready flag)
@@ -1637,6 +1637,7 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
         }
         const unsigned nb = n_walk + (unsigned)(G.n_chunks * groups);
         switch (impl) {
+            case 17: k_decode_lanes<64, 16, 64, 32, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
             case 15: k_decode_lanes<64, 32, 64, 16, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
             case 14: k_decode_lanes<32, 16, 64, 8, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
             case 8: k_decode_lanes<64, 16, 64, 16, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;

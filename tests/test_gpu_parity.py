@@ -43,7 +43,7 @@ def gpu_encode(ctx, plan, x):
     return enc, w, off
 
 
-IMPLS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 14, 15, 16]
+IMPLS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 14, 15, 16, 17]
 
 
 # --------------------------------------------------------------------------- golden
@@ -270,6 +270,42 @@ def test_large_batch_properties(ctx, O):
         assert enc.chunk_bytes(c) == O.encode_chunk(xc, (8, L)).tobytes()
     # idempotence: encoding the decoded batch gives the same stream
     enc2 = plan.encode(y)
+    assert enc2.total_words == enc.total_words
+    assert torch.equal(enc2.words[:enc2.total_words], enc.words[:enc.total_words])
+
+
+def test_full_size_headline_batch(ctx, O):
+    """BASELINE config #2 at FULL size (1M x 7000 int16, 500 chunks of 2000 x 7000, m = 8), through what does
+    not depend on the size: round trip, the framing's checksum of checksums, header words, spot chunks
+    against the oracle bit for bit, idempotence.  About 45 GB of HBM, a few seconds."""
+    free, _ = torch.cuda.mem_get_info(ctx.device)
+    if free < 60 * 2**30:
+        pytest.skip("needs 60 GB of free HBM")
+    n_chunks, W, L = 500, 2000, 7000
+    x = torch.empty(n_chunks * W * L, dtype=torch.int16, device=ctx.device)
+    g = torch.Generator(device=ctx.device).manual_seed(4242)
+    slab = 25 * W * L
+    for s0 in range(0, x.numel(), slab):
+        x[s0:s0 + slab] = torch.randn(slab, device=ctx.device, generator=g).mul_(10.0).to(torch.int16)
+    torch.cuda.synchronize()
+    plan = ctx.plan_uniform(n_chunks, W * L, (8, L))
+    enc = plan.encode(x)
+    nw = plan.wave_words().reshape(n_chunks, W)  # n_i as the encoder counted them
+    y = plan.decode(enc)
+    assert torch.equal(x, y)
+    ratio = enc.total_words * 4 / (x.numel() * 2)
+    assert 0.4035 < ratio < 0.4050  # BASELINE.md section 2: 0.4043
+    off = enc.chunk_word_off.cpu().numpy()
+    assert off[0] == 0 and off[-1] == enc.total_words
+    assert np.array_equal(np.diff(off), 1 + W + nw.sum(axis=1, dtype=np.uint64))  # checksum of the framing
+    assert np.array_equal(plan.wave_words().reshape(n_chunks, W), nw)               # the decoder's walk found the same n_i
+    hdr = enc.words[torch.from_numpy(off[:-1].astype(np.int64)).to(ctx.device)].cpu().numpy()
+    assert np.all(hdr == W * L)
+    for c in (0, 123, 499):
+        xc = x[c * W * L:(c + 1) * W * L].cpu().numpy()
+        assert enc.chunk_bytes(c) == O.encode_chunk(xc, (8, L)).tobytes()
+    del y
+    enc2 = plan.encode(x)
     assert enc2.total_words == enc.total_words
     assert torch.equal(enc2.words[:enc2.total_words], enc.words[:enc.total_words])
 

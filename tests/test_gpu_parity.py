@@ -310,6 +310,37 @@ def test_full_size_headline_batch(ctx, O):
     assert torch.equal(enc2.words[:enc2.total_words], enc.words[:enc.total_words])
 
 
+def test_one_huge_chunk_near_the_format_limit(ctx, O):
+    """One chunk of 1.5e9 samples (the format allows 2^31 - 1, src/deltaRice.c:389): 32-bit index arithmetic,
+    a leftover waveform, 214 286 hops in one header chain.  Round trip, framing, spot waveforms vs the oracle."""
+    free, _ = torch.cuda.mem_get_info(ctx.device)
+    if free < 24 * 2**30:
+        pytest.skip("needs 24 GB of free HBM")
+    L, W_full, left = 7000, 214285, 123
+    N = W_full * L + left
+    g = torch.Generator(device=ctx.device).manual_seed(99)
+    x = torch.empty(N, dtype=torch.int16, device=ctx.device)
+    slab = 30000 * L
+    for s0 in range(0, N, slab):
+        n = min(slab, N - s0)
+        x[s0:s0 + n] = torch.randn(n, device=ctx.device, generator=g).mul_(10.0).to(torch.int16)
+    torch.cuda.synchronize()
+    plan = ctx.plan_uniform(1, N, (8, L))
+    assert plan.total_waves == W_full + 1
+    enc = plan.encode(x)
+    nw = plan.wave_words()
+    assert torch.equal(plan.decode(enc), x)
+    off = enc.chunk_word_off.cpu().numpy()
+    assert int(off[1]) == 1 + (W_full + 1) + int(nw.sum(dtype=np.uint64))
+    assert int(enc.words[0].item()) == N
+    starts = 1 + np.concatenate([[0], np.cumsum(nw.astype(np.uint64) + 1)[:-1]]).astype(np.int64)
+    for w in (0, 1, 100000, W_full - 1, W_full):  # the last one is the 123-sample leftover
+        xs = x[w * L:min((w + 1) * L, N)].cpu().numpy()
+        ref = O.encode_chunk(xs, (8, L))  # one-waveform chunk: [n_samples, n_0, payload...]
+        got = enc.words[int(starts[w]):int(starts[w]) + 1 + int(nw[w])].cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, ref[1:]), w
+
+
 def test_general_prediction_filters_vs_oracle(ctx, O):
     """cd_nelmts >= 3 (src/deltaRice.c:64-74,91-102): FIR forward / IIR inverse on the GPU, compared with the
     oracle for taps the reference's own tests and docs use (tests/test.py:46-83, docs/Optimization.md:21)."""

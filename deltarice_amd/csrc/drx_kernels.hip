@@ -403,9 +403,11 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
 }
 
 // Packed code parameters of the 8 samples a lane holds as 4 dwords (low half = earlier sample).
-//   nb  code length, r  payload bits (k low bits of z, or all 16 for an escape),
-//   kk  payload width = position of the terminating '1' above the payload.
-struct PackedCodes { uint32_t nb[4], r[4], kk[4]; };
+//   nb   code length,
+//   c16  the code's low 16 bits: payload with the terminating '1' above it (k low bits of z | 1 << k), or the
+//        16 payload bits of an escape, whose terminator is bit 16:
+//   e    1 for an escape, else 0.  The code word is (e << 16) | c16, its leading zeros are implicit.
+struct PackedCodes { uint32_t nb[4], c16[4], e[4]; };
 
 // x[j]: samples 2j, 2j+1; xprev: dword whose HIGH half is the sample just before x[0]'s low half.
 __device__ __forceinline__ void packed_codes(const uint32_t x[4], uint32_t xprev, uint32_t k, PackedCodes &c) {
@@ -427,10 +429,16 @@ __device__ __forceinline__ void packed_codes(const uint32_t x[4], uint32_t xprev
     for (int j = 0; j < 4; ++j) e[j] = qc[j] >> (uint16_t)3;                                         // 1 = escape (:215)
 #pragma unroll
     for (int j = 0; j < 4; ++j) c.nb[j] = as_u32(e[j] * c16k + (qc[j] + kp1));   // q+1+k, or 8+1+16
+    u16x2 r[4], one[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) c.r[j] = as_u32(z[j] & (e[j] * mdelta + mlo));   // z & (M-1), or z
+    for (int j = 0; j < 4; ++j) r[j] = z[j] & (e[j] * mdelta + mlo);             // z & (M-1), or z
 #pragma unroll
-    for (int j = 0; j < 4; ++j) c.kk[j] = as_u32(e[j] * c16k + kv);              // k, or 16
+    for (int j = 0; j < 4; ++j) one[j] = (e[j] ^ splat(1u)) << kv;               // 1 << k, or 0 (bit 16 is c.e)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        c.c16[j] = as_u32(r[j] | one[j]);
+        c.e[j] = as_u32(e[j]);
+    }
 }
 
 constexpr uint32_t kEncCapWords = 2048;  // LDS words per waveform buffer (8 KB): 9.3 bits/sample at L = 7000
@@ -481,9 +489,8 @@ __device__ __forceinline__ void emit_tile(const PackedCodes &c, uint32_t pb) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const uint32_t n = (j & 1) ? (c.nb[j >> 1] >> 16) : (c.nb[j >> 1] & 0xffffu);
-        const uint32_t r = (j & 1) ? (c.r[j >> 1] >> 16) : (c.r[j >> 1] & 0xffffu);
-        const uint32_t kk = (j & 1) ? (c.kk[j >> 1] >> 16) : (c.kk[j >> 1] & 0xffffu);
-        uint32_t code32 = (1u << kk) | r;  // terminator + payload; the leading zeros are implicit
+        // terminator + payload; the leading zeros are implicit
+        uint32_t code32 = __builtin_amdgcn_perm(c.e[j >> 1], c.c16[j >> 1], (j & 1) ? 0x07060302u : 0x05040100u);
         if (!FULL) code32 = n ? code32 : 0u;
         const uint32_t pe = pb + n;        // end of this code = start of the next
         // left-align the code at bit (pb & 31) of a 64-bit window: shift = 64 - (pb & 31) - n,
@@ -508,11 +515,9 @@ __device__ __forceinline__ void concat_codes(const PackedCodes &c, uint32_t (&w)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         // v_alignbit_b32 / v_lshl_or_b32 read 5 bits of the shift: for the low half the packed register serves as is
-        const uint32_t nbj = c.nb[j >> 1], rj = c.r[j >> 1], kkj = c.kk[j >> 1];
+        const uint32_t nbj = c.nb[j >> 1];
         const uint32_t n = (j & 1) ? (nbj >> 16) : nbj;
-        const uint32_t r = (j & 1) ? (rj >> 16) : (rj & 0xffffu);
-        const uint32_t kk = (j & 1) ? (kkj >> 16) : kkj;
-        const uint32_t code32 = (1u << (kk & 31u)) | r;
+        const uint32_t code32 = __builtin_amdgcn_perm(c.e[j >> 1], c.c16[j >> 1], (j & 1) ? 0x07060302u : 0x05040100u);
         const uint32_t s = 0u - n;  // == 32 - n (mod 32)
         if (j >= 3) w3 = __builtin_amdgcn_alignbit(w3, w2, s);
         if (j >= 2) w2 = __builtin_amdgcn_alignbit(w2, w1, s);

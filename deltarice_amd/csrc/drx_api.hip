@@ -386,8 +386,7 @@ static drx_status decode_launch(drx_plan *p, const uint32_t *d_in, uint64_t in_w
     DRX_HIP(ctx, launch_decode(p->G, d_in, in_words, d_chunk_word_off, d_out, p->d_wave_off,
                                p->d_wave_words, p->d_scan, p->d_status,
                                (tables_ready ? 100 : 0) + (p->G.n_taps ? 0 : ctx->decode_impl),
-                               p->d_walk_lists, p->n_short, p->d_walk_lists ? p->d_walk_lists + p->n_short : nullptr,
-                               p->n_long, ctx->profile ? p->ev : nullptr, ctx->stream));
+                               ctx->profile ? p->ev : nullptr, ctx->stream));
     p->ev_valid = ctx->profile != 0;
     p->last_was_encode = false;
     return DRX_OK;

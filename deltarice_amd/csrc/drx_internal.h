@@ -30,8 +30,13 @@ struct Geom {
     // FIR / IIR kernels.
     uint32_t n_taps;
     const int32_t *taps;
-    uint32_t dbg;  // ablation switches for profiling builds of the decode kernel (0 in normal use):
-                   // bit 0: skip the output stores, bit 1: skip the stream loads
+    uint32_t dbg;  // ablation / A-B switches ("debug_flags" context option; 0 in normal use, results are
+                   // invalid with bits 0, 1, 5, 6, 7):
+                   //   decode:   1 skip the output stores        2 skip the stream loads
+                   //             4 request pieces without counting on the round's minimum consumption
+                   //             8 walk with vector loads, 64 chunks per wave (the pre-scalar-load walk)
+                   //   encode:  16 per-code LDS emission instead of the lane-local concatenation
+                   //            32 no emission   64 no copy-out   128 no look-back (positions wrong)
     // ragged batches, walk inside the decode launch: chunk indices, short-waveform chunks first
     // (walk_short[n_short], then walk_long[n_long]), and the largest ceil(n_waves / 64) of any chunk
     const uint32_t *walk_short, *walk_long;
@@ -61,7 +66,6 @@ hipError_t launch_encode_fused(const Geom &G, const int16_t *d_in, uint32_t *d_o
 hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                          const uint64_t *d_chunk_word_off, int16_t *d_out, uint64_t *d_wave_off,
                          uint32_t *d_wave_words, uint64_t *d_granules, DevStatus *d_status, int impl,
-                         const uint32_t *d_short_list, uint32_t n_short, const uint32_t *d_long_list, uint32_t n_long,
                          hipEvent_t *ev, hipStream_t s);
 constexpr uint32_t kWalkShortLenHost = 2048;  // keep equal to kWalkShortLen in drx_kernels.hip
 

@@ -1608,7 +1608,6 @@ hipError_t launch_encode(const Geom &G, const int16_t *d_in, uint32_t *d_out, ui
 hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                          const uint64_t *d_chunk_word_off, int16_t *d_out, uint64_t *d_wave_off,
                          uint32_t *d_wave_words, uint64_t *d_granules, DevStatus *d_status, int impl,
-                         const uint32_t *d_short_list, uint32_t n_short, const uint32_t *d_long_list, uint32_t n_long,
                          hipEvent_t *ev, hipStream_t s) {
     if (G.total_waves == 0) return hipSuccess;
     mark(ev, 0, s);
@@ -1663,10 +1662,10 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                 k_walk_scalar<<<blocks_for(G.n_chunks, kWalkChains), 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off,
                                                                                  d_wave_off, d_wave_words, d_status);
         } else {
-            if (n_short) k_walk_block<<<n_short, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_short_list, n_short,
-                                                             d_wave_off, d_wave_words, d_status);
-            if (n_long) k_walk_list<<<blocks_for(n_long, 64), 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_long_list,
-                                                                         n_long, d_wave_off, d_wave_words, d_status);
+            if (G.n_short) k_walk_block<<<G.n_short, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, G.walk_short, G.n_short,
+                                                                 d_wave_off, d_wave_words, d_status);
+            if (G.n_long) k_walk_list<<<blocks_for(G.n_long, 64), 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, G.walk_long,
+                                                                             G.n_long, d_wave_off, d_wave_words, d_status);
         }
         mark(ev, 1, s);
         const unsigned nb = blocks_for(G.total_waves, 64);

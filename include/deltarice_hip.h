@@ -140,8 +140,16 @@ drx_status drx_filter_chunk_host(drx_ctx *ctx, int reverse, size_t cd_nelmts,
  *   after drx_decode: ms = { header-chain walk, decode kernel, 0, whole call } */
 drx_status drx_plan_last_timings(drx_plan *plan, float ms[4]);
 
-/* Tuning / diagnostics: "decode_impl" selects a decode kernel variant, "profile"
- * turns the event bracketing above on.  Returns DRX_ERR_ARG for unknown keys. */
+/* Tuning / diagnostics.  Returns DRX_ERR_ARG for unknown keys or values.
+ *   "profile"      1: bracket the kernels with HIP events (drx_plan_last_timings)
+ *   "encode_impl"  1 (default): single pass with look-back;  0: size pass + scan + pack pass
+ *   "decode_impl"  variant of the decode kernel; every one is bit-exact and covered by the parity tests:
+ *        8 (default)  header walk inside the launch, 64-word ring, two samples per ring access
+ *        7            the same with a separate walk kernel        5 / 1  one sample per access (fused / separate)
+ *        15 / 16      128-byte stream pieces (fused / separate)   17     32-sample groups
+ *        14 / 11, 6 / 2, 3   32-word ring geometries              9, 10  32-sample rounds
+ *        4            128-word ring                               0      simple kernel (also: general filters)
+ *   "debug_flags"  kernel ablation switches for profiling (see csrc/drx_internal.h); results may be invalid */
 drx_status drx_ctx_set_option(drx_ctx *ctx, const char *key, int64_t value);
 
 #ifdef __cplusplus

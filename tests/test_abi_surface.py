@@ -102,3 +102,18 @@ def test_filter_callback_fails_loudly_without_gpu(capfd):
     from deltarice_amd import codec, DeltaRiceError
     with pytest.raises(DeltaRiceError):
         codec.Context(0)
+
+
+def test_reference_import_path_alias():
+    """`import deltaRice.h5` (the reference's module path) resolves to this codec; it needs h5py,
+    which this image lacks, so only the failure mode can be checked here."""
+    import importlib
+    import deltaRice  # noqa: F401
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError):
+            importlib.import_module("deltaRice.h5")
+    else:
+        m = importlib.import_module("deltaRice.h5")
+        assert m.H5FILTER == 32025 and callable(m.register_h5_filter)

@@ -1396,9 +1396,10 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
                 const uint32_t z1 = (q1 << kk1) + __builtin_amdgcn_ubfe(winA, nu1, kk1);
                 const uint32_t z2 = (q2 << kk2) + __builtin_amdgcn_ubfe(win2, nu2, kk2);
                 acc += (int32_t)(z1 >> 1) ^ -(int32_t)(z1 & 1u);
-                const uint32_t a1 = (uint32_t)acc & 0xffffu;
+                const uint32_t a1 = (uint32_t)acc;
                 acc += (int32_t)(z2 >> 1) ^ -(int32_t)(z2 & 1u);
-                *reinterpret_cast<uint32_t *>(myout + tg + u) = a1 | ((uint32_t)acc << 16);
+                // low halves of the two running sums in one v_perm_b32
+                *reinterpret_cast<uint32_t *>(myout + tg + u) = __builtin_amdgcn_perm((uint32_t)acc, a1, 0x05040100u);
             }
             return;
         }

@@ -328,10 +328,16 @@ drx_status drx_plan_set_filter(drx_plan *p, uint32_t n_taps, const int32_t *taps
     if (taps[0] == 0) return fail(ctx, DRX_ERR_ARG, "taps[0] must not be 0 (the inverse filter divides by it)");
     DRX_HIP(ctx, hipSetDevice(ctx->device));
     DRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    p->G.fast_taps = 0;
     if (n_taps == 2 && taps[0] == 1 && taps[1] == -1) {  // checkIfDeltaFilter, src/deltaRice.c:38-46
         p->G.n_taps = 0;
         p->G.taps = nullptr;
         return DRX_OK;
+    }
+    if (n_taps <= 4 && (taps[0] == 1 || taps[0] == -1)) {
+        p->G.fast_taps = 1;
+        p->G.fast_t0neg = taps[0] == -1;
+        for (uint32_t j = 1; j < 4; ++j) p->G.fast_nt[j - 1] = (j < n_taps) ? 0u - (uint32_t)taps[j] : 0u;
     }
     if (!p->d_taps) DRX_HIP(ctx, hipMalloc((void **)&p->d_taps, DRX_MAX_TAPS * sizeof(int32_t)));
     DRX_HIP(ctx, hipMemcpy(p->d_taps, taps, n_taps * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -385,7 +391,7 @@ static drx_status decode_launch(drx_plan *p, const uint32_t *d_in, uint64_t in_w
     p->G.dbg = ctx->debug_flags;
     DRX_HIP(ctx, launch_decode(p->G, d_in, in_words, d_chunk_word_off, d_out, p->d_wave_off,
                                p->d_wave_words, p->d_scan, p->d_status,
-                               (tables_ready ? 100 : 0) + (p->G.n_taps ? 0 : ctx->decode_impl),
+                               (tables_ready ? 100 : 0) + ctx->decode_impl,
                                ctx->profile ? p->ev : nullptr, ctx->stream));
     p->ev_valid = ctx->profile != 0;
     p->last_was_encode = false;

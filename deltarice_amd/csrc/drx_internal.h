@@ -30,6 +30,10 @@ struct Geom {
     // FIR / IIR kernels.
     uint32_t n_taps;
     const int32_t *taps;
+    // general filters the fast kernels take: at most 4 taps with taps[0] = +-1 (the inverse filter then has no
+    // division); fast_t0neg = (taps[0] == -1), fast_nt[j-1] = -taps[j] (0 beyond n_taps)
+    uint32_t fast_taps, fast_t0neg;
+    uint32_t fast_nt[3];
     uint32_t dbg;  // ablation / A-B switches ("debug_flags" context option; 0 in normal use, results are
                    // invalid with bits 0, 1, 5, 6, 7):
                    //   decode:   1 skip the output stores        2 skip the stream loads

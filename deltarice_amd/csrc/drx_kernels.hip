@@ -1155,7 +1155,7 @@ __global__ __launch_bounds__(64) void k_decode_simple(Geom G, const uint32_t *__
 //               so the ~1.7 ms of dependent-load latency of the walk disappears behind the decode.
 //               A ticket holder is by construction running, so waiting on a lower ticket's walker
 //               cannot deadlock whatever the dispatch order.  (Uniform batches only.)
-template <int RW, int LW, int T, int GS, bool FUSED, bool PAIR = false, bool CAP2 = false>
+template <int RW, int LW, int T, int GS, bool FUSED, bool PAIR = false, bool CAP2 = false, bool GEN = false>
 __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
                                                      const uint64_t *__restrict__ chunk_word_off,
                                                      uint64_t *__restrict__ wave_off,
@@ -1370,6 +1370,25 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
         wave_sync();
     }
     int32_t acc = 0;
+    // GEN: inverse of a general prediction filter with taps[0] = +-1 and at most 4 taps (src/deltaRice.c:92-101):
+    // y[i] = +-(d[i] - sum_{j=1..3} taps[j] y[i-j]) in int16, i.e. modulo 2^16 (only the low 16 bits of the
+    // products count, so 24-bit multiplies of whatever the registers hold above bit 15 are exact).
+    // acc is y[i-1]; y2, y3 the two before it; all zero before the waveform (:96 `if ((i - j) >= 0)`).
+    int32_t y2 = 0, y3 = 0;
+    const uint32_t nt1 = GEN ? G.fast_nt[0] & 0xffffu : 0u, nt2 = GEN ? G.fast_nt[1] & 0xffffu : 0u,
+                   nt3 = GEN ? G.fast_nt[2] & 0xffffu : 0u;
+    const bool t0neg = GEN && G.fast_t0neg;
+    auto advance = [&](int32_t d) __attribute__((always_inline)) {
+        if constexpr (GEN) {
+            uint32_t a = (uint32_t)d + __umul24(nt1, (uint32_t)acc) + __umul24(nt2, (uint32_t)y2) + __umul24(nt3, (uint32_t)y3);
+            if (t0neg) a = 0u - a;
+            y3 = y2;
+            y2 = acc;
+            acc = (int32_t)a;
+        } else {
+            acc += d;
+        }
+    };
 
     auto decode_group = [&](auto first_tag, int tg) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_tag)::value;
@@ -1395,9 +1414,9 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
                 asm("v_add3_u32 %0, %1, %2, %3" : "=v"(Q) : "v"(Q), "v"(nu1), "v"(nu2));
                 const uint32_t z1 = (q1 << kk1) + __builtin_amdgcn_ubfe(winA, nu1, kk1);
                 const uint32_t z2 = (q2 << kk2) + __builtin_amdgcn_ubfe(win2, nu2, kk2);
-                acc += (int32_t)(z1 >> 1) ^ -(int32_t)(z1 & 1u);
+                advance((int32_t)(z1 >> 1) ^ -(int32_t)(z1 & 1u));
                 const uint32_t a1 = (uint32_t)acc;
-                acc += (int32_t)(z2 >> 1) ^ -(int32_t)(z2 & 1u);
+                advance((int32_t)(z2 >> 1) ^ -(int32_t)(z2 & 1u));
                 // low halves of the two running sums in one v_perm_b32
                 *reinterpret_cast<uint32_t *>(myout + tg + u) = __builtin_amdgcn_perm((uint32_t)acc, a1, 0x05040100u);
             }
@@ -1418,10 +1437,14 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
             const int32_t d = (int32_t)(z >> 1) ^ -(int32_t)(z & 1u);
             if (FIRST) {
                 const bool act = (uint32_t)(tg + u) >= phi;
-                acc = act ? acc + d : acc;
+                const int32_t o1 = acc, o2 = y2, o3 = y3;
+                advance(d);
+                acc = act ? acc : o1;
+                y2 = act ? y2 : o2;
+                y3 = act ? y3 : o3;
                 Q = act ? Q - used : Q;
             } else {
-                acc += d;
+                advance(d);
                 Q -= used;
             }
             myout[tg + u] = (uint16_t)acc;
@@ -1616,6 +1639,11 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
     // chain on the CPU while the chunk is in flight to the device): decode with variant impl - 100, no walk
     const bool tables_ready = impl >= 100;
     if (tables_ready) impl -= 100;
+    // general prediction filters: the staged kernel where it has no division to do, else the simple kernel
+    const bool gen = G.n_taps != 0;
+    if (gen && !G.fast_taps) impl = 0;
+    if (gen && G.fast_taps) impl = (impl == 0) ? 0 : ((impl == 1 || impl == 2 || impl == 3 || impl == 4 || impl == 7 || impl == 9 ||
+                                                       impl == 10 || impl == 11 || impl == 16) ? 7 : 8);
     if (tables_ready && (impl == 5 || impl == 6)) impl = 1;
     if (tables_ready && (impl == 8 || impl == 14 || impl == 15 || impl == 17)) impl = 7;
     // the walk runs inside the decode launch; batches that need the LDS block walk (ragged ones, short
@@ -1645,7 +1673,9 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
             case 17: k_decode_lanes<64, 16, 64, 32, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
             case 15: k_decode_lanes<64, 32, 64, 16, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
             case 14: k_decode_lanes<32, 16, 64, 8, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
-            case 8: k_decode_lanes<64, 16, 64, 16, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
+            case 8:
+                if (gen) { k_decode_lanes<64, 16, 64, 16, true, true, false, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break; }
+                k_decode_lanes<64, 16, 64, 16, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
             case 6: k_decode_lanes<32, 16, 64, 8, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
             default: k_decode_lanes<64, 16, 64, 16, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
         }
@@ -1678,7 +1708,9 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
             case 9: k_decode_lanes<32, 16, 32, 8, false, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
             case 10: k_decode_lanes<64, 16, 32, 16, false, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
             case 11: k_decode_lanes<32, 16, 64, 8, false, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
-            case 7: k_decode_lanes<64, 16, 64, 16, false, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
+            case 7:
+                if (gen) { k_decode_lanes<64, 16, 64, 16, false, true, false, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break; }
+                k_decode_lanes<64, 16, 64, 16, false, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
             case 2: k_decode_lanes<32, 16, 64, 8, false><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
             case 3: k_decode_lanes<32, 8, 64, 8, false><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
             case 4: k_decode_lanes<128, 16, 64, 16, false><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;

@@ -346,17 +346,22 @@ def test_general_prediction_filters_vs_oracle(ctx, O):
     oracle for taps the reference's own tests and docs use (tests/test.py:46-83, docs/Optimization.md:21)."""
     rng = np.random.default_rng(77)
     x = rng.normal(0, 40, 3 * 5000).astype(np.int16)
-    for taps in [(1,), (1, -1, 1, -1), (-1, 1), (1, -2, 1), (2, -1), (1, 0, 0, -1)]:
+    for taps in [(1,), (1, -1, 1, -1), (-1, 1), (1, -2, 1), (2, -1), (1, 0, 0, -1), (-1, 3, -3, 1), (1, 70000, -5),
+                 (1, -1, 1, -1, 1)]:
         opts = (8, 1000, len(taps)) + tuple(t & 0xFFFFFFFF for t in taps)
         ref_w, ref_off = O.encode_batch(x, 5000, opts)
         plan = ctx.plan_uniform(3, 5000, opts)
         enc = plan.encode(dev(ctx, x))
         w, off = enc.to_numpy()
         assert np.array_equal(off, ref_off) and np.array_equal(w, ref_w), taps
-        y = plan.decode(enc).cpu().numpy()
-        assert np.array_equal(y, O.decode_batch(ref_w, ref_off, 5000, opts)), taps  # lossy taps[0] included
-        if abs(taps[0]) == 1:
-            assert np.array_equal(y, x), taps
+        ref_y = O.decode_batch(ref_w, ref_off, 5000, opts)
+        for impl in (0, 7, 8):  # simple kernel; staged kernel (taken when taps[0] = +-1 and <= 4 taps), walk separate / fused
+            ctx.set_option("decode_impl", impl)
+            y = plan.decode(enc).cpu().numpy()
+            assert np.array_equal(y, ref_y), (taps, impl)  # lossy taps[0] included
+            if abs(taps[0]) == 1:
+                assert np.array_equal(y, x), (taps, impl)
+        ctx.set_option("decode_impl", 8)
 
 
 def test_rice_parameter_optimiser_is_exact(ctx, O):

@@ -329,10 +329,15 @@ drx_status drx_plan_set_filter(drx_plan *p, uint32_t n_taps, const int32_t *taps
     DRX_HIP(ctx, hipSetDevice(ctx->device));
     DRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     p->G.fast_taps = 0;
+    p->G.enc_fast = 0;
     if (n_taps == 2 && taps[0] == 1 && taps[1] == -1) {  // checkIfDeltaFilter, src/deltaRice.c:38-46
         p->G.n_taps = 0;
         p->G.taps = nullptr;
         return DRX_OK;
+    }
+    if (n_taps <= 4) {
+        p->G.enc_fast = 1;
+        for (uint32_t j = 0; j < 4; ++j) p->G.enc_t[j] = (j < n_taps) ? (uint32_t)taps[j] & 0xffffu : 0u;
     }
     if (n_taps <= 4 && (taps[0] == 1 || taps[0] == -1)) {
         p->G.fast_taps = 1;
@@ -370,7 +375,7 @@ drx_status drx_encode(drx_plan *p, const int16_t *d_in, uint32_t *d_out, uint64_
     drx_ctx *ctx = p->ctx;
     DRX_HIP(ctx, hipSetDevice(ctx->device));
     DRX_HIP(ctx, hipMemsetAsync(p->d_status, 0, sizeof(DevStatus), ctx->stream));
-    if (ctx->encode_impl == 1 && p->G.n_taps == 0)
+    if (ctx->encode_impl == 1 && (p->G.n_taps == 0 || p->G.enc_fast))
         DRX_HIP(ctx, launch_encode_fused(p->G, d_in, d_out, out_cap_words, d_chunk_word_off, p->d_wave_words,
                                          p->d_scan, p->d_status, ctx->profile ? p->ev : nullptr, ctx->stream));
     else

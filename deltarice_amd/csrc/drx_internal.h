@@ -34,6 +34,9 @@ struct Geom {
     // division); fast_t0neg = (taps[0] == -1), fast_nt[j-1] = -taps[j] (0 beyond n_taps)
     uint32_t fast_taps, fast_t0neg;
     uint32_t fast_nt[3];
+    // forward filter in the single-pass encoder: at most 4 taps, any taps[0]; enc_t[j] = taps[j] mod 2^16
+    uint32_t enc_fast;
+    uint32_t enc_t[4];
     uint32_t dbg;  // ablation / A-B switches ("debug_flags" context option; 0 in normal use, results are
                    // invalid with bits 0, 1, 5, 6, 7):
                    //   decode:   1 skip the output stores        2 skip the stream loads

@@ -410,7 +410,11 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
 struct PackedCodes { uint32_t nb[4], c16[4], e[4]; };
 
 // x[j]: samples 2j, 2j+1; xprev: dword whose HIGH half is the sample just before x[0]'s low half.
-__device__ __forceinline__ void packed_codes(const uint32_t x[4], uint32_t xprev, uint32_t k, PackedCodes &c) {
+// GEN: general forward filter (src/deltaRice.c:64-74) d[i] = sum_j taps[j] x[i-j] modulo 2^16, at most four taps
+// (tp[j] = taps[j] in both halves); xprev2: the dword before xprev (samples i-4, i-3 of the lane's first pair).
+template <bool GEN>
+__device__ __forceinline__ void packed_codes(const uint32_t x[4], uint32_t xprev, uint32_t xprev2, const u16x2 (&tp)[4],
+                                             uint32_t k, PackedCodes &c) {
     const u16x2 kv = splat(k), kp1 = splat(k + 1u), c16k = splat(16u - k);
     const u16x2 mlo = splat((1u << k) - 1u), mdelta = splat(0xffffu - ((1u << k) - 1u));
     // stage by stage over the four dwords rather than dword by dword: consecutive instructions are then
@@ -418,8 +422,17 @@ __device__ __forceinline__ void packed_codes(const uint32_t x[4], uint32_t xprev
     u16x2 z[4], qc[4], e[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const uint32_t before = __builtin_amdgcn_alignbit(x[j], j ? x[j - 1] : xprev, 16);  // samples 2j-1, 2j
-        const i16x2 d = as_i16x2(x[j]) - as_i16x2(before);                                   // :51-63, mod 2^16
+        const uint32_t xm1 = j ? x[j - 1] : xprev;                                           // samples 2j-2, 2j-1
+        const uint32_t before = __builtin_amdgcn_alignbit(x[j], xm1, 16);                    // samples 2j-1, 2j
+        i16x2 d;
+        if (GEN) {
+            const uint32_t xm2 = j >= 2 ? x[j - 2] : (j == 1 ? xprev : xprev2);
+            const uint32_t before3 = __builtin_amdgcn_alignbit(xm1, xm2, 16);                // samples 2j-3, 2j-2
+            d = __builtin_bit_cast(i16x2, (u16x2)(as_u16x2(x[j]) * tp[0] + as_u16x2(before) * tp[1] +
+                                                  as_u16x2(xm1) * tp[2] + as_u16x2(before3) * tp[3]));
+        } else {
+            d = as_i16x2(x[j]) - as_i16x2(before);                                           // :51-63, mod 2^16
+        }
         z[j] = __builtin_bit_cast(u16x2, (i16x2)(d << (int16_t)1)) ^
                __builtin_bit_cast(u16x2, (i16x2)(d >> (int16_t)15));                         // zig-zag :207-211
     }
@@ -551,6 +564,7 @@ __device__ __forceinline__ uint32_t lds_addr(const uint32_t *p) {
 
 constexpr int kEncWaves = 8;  // waveforms (wavefronts) per workgroup = per ticket
 
+template <bool GEN>
 __global__ __launch_bounds__(64 * kEncWaves) void k_encode_fused(Geom G, const int16_t *__restrict__ in,
                                                       uint32_t *__restrict__ out, uint64_t out_cap,
                                                       uint64_t *__restrict__ chunk_word_off,
@@ -590,6 +604,9 @@ __global__ __launch_bounds__(64 * kEncWaves) void k_encode_fused(Geom G, const i
     uint64_t P = 0;        // bits so far (wave uniform)
     bool fits = true;      // everything so far is in buf (wave uniform)
     uint32_t carry = 0;    // dword whose high half is the sample before the tile (x[-1] := 0, :53-54)
+    uint32_t carry2 = 0;   // GEN: the dword before that one (samples -4, -3)
+    const u16x2 tp[4] = {splat(GEN ? G.enc_t[0] : 1u), splat(GEN ? G.enc_t[1] : 0xffffu), splat(GEN ? G.enc_t[2] : 0u),
+                         splat(GEN ? G.enc_t[3] : 0u)};
     // Full tiles run in a loop without any masking, with the next tile's 16-byte load in flight
     // while the current one is packed; the trailing partial tile (if any) takes the masked path once.
     auto process_tile = [&](const uint32_t (&w)[4], int nv, auto full_tag) {
@@ -597,8 +614,14 @@ __global__ __launch_bounds__(64 * kEncWaves) void k_encode_fused(Geom G, const i
         uint32_t xprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[3], 0x138, 0xf, 0xf, false);  // wave_shr:1
         if (lane == 0) xprev = carry;
         carry = (uint32_t)__builtin_amdgcn_readlane((int)w[3], 63);
+        uint32_t xprev2 = 0;
+        if (GEN) {
+            xprev2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[2], 0x138, 0xf, 0xf, false);  // wave_shr:1
+            if (lane == 0) xprev2 = carry2;
+            carry2 = (uint32_t)__builtin_amdgcn_readlane((int)w[2], 63);
+        }
         PackedCodes c;
-        packed_codes(w, xprev, k, c);
+        packed_codes<GEN>(w, xprev, xprev2, tp, k, c);
         if (!FULLT) mask_tail(c, nv);
         const uint32_t lane_bits = lane_tile_bits(c);
         uint32_t cw[4];
@@ -757,14 +780,21 @@ __global__ __launch_bounds__(64 * kEncWaves) void k_encode_fused(Geom G, const i
     wave_sync();
     P = 0;
     carry = 0;
+    carry2 = 0;
     for (uint32_t t0 = 0; t0 < r.len; t0 += kTile) {
         uint32_t w[4];
         const int nv = load8_dwords(x, r.len, t0, lane, vec_ok, w);
         uint32_t xprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[3], 0x138, 0xf, 0xf, false);
         if (lane == 0) xprev = carry;
         carry = (uint32_t)__shfl((int)w[3], 63);
+        uint32_t xprev2 = 0;
+        if (GEN) {
+            xprev2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[2], 0x138, 0xf, 0xf, false);
+            if (lane == 0) xprev2 = carry2;
+            carry2 = (uint32_t)__shfl((int)w[2], 63);
+        }
         PackedCodes c;
-        packed_codes(w, xprev, k, c);
+        packed_codes<GEN>(w, xprev, xprev2, tp, k, c);
         mask_tail(c, nv);
         const uint32_t lane_bits = lane_tile_bits(c);
         const uint32_t incl = wave_incl_scan_dpp(lane_bits);
@@ -1606,8 +1636,12 @@ hipError_t launch_encode_fused(const Geom &G, const int16_t *d_in, uint32_t *d_o
     mark(ev, 1, s);
     mark(ev, 2, s);
     uint32_t *ticket = reinterpret_cast<uint32_t *>(d_scan + G.total_waves);
-    k_encode_fused<<<blocks_for(G.total_waves, kEncWaves), 64 * kEncWaves, 0, s>>>(G, d_in, d_out, out_cap, d_chunk_word_off,
-                                                                d_wave_words, d_scan, ticket, d_status);
+    if (G.n_taps)
+        k_encode_fused<true><<<blocks_for(G.total_waves, kEncWaves), 64 * kEncWaves, 0, s>>>(G, d_in, d_out, out_cap, d_chunk_word_off,
+                                                                                      d_wave_words, d_scan, ticket, d_status);
+    else
+        k_encode_fused<false><<<blocks_for(G.total_waves, kEncWaves), 64 * kEncWaves, 0, s>>>(G, d_in, d_out, out_cap, d_chunk_word_off,
+                                                                                       d_wave_words, d_scan, ticket, d_status);
     mark(ev, 3, s);
     return hipGetLastError();
 }

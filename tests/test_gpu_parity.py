@@ -351,9 +351,11 @@ def test_general_prediction_filters_vs_oracle(ctx, O):
         opts = (8, 1000, len(taps)) + tuple(t & 0xFFFFFFFF for t in taps)
         ref_w, ref_off = O.encode_batch(x, 5000, opts)
         plan = ctx.plan_uniform(3, 5000, opts)
-        enc = plan.encode(dev(ctx, x))
-        w, off = enc.to_numpy()
-        assert np.array_equal(off, ref_off) and np.array_equal(w, ref_w), taps
+        for eimpl in (0, 1):  # two-pass encoder; single-pass encoder (takes up to 4 taps)
+            ctx.set_option("encode_impl", eimpl)
+            enc = plan.encode(dev(ctx, x))
+            w, off = enc.to_numpy()
+            assert np.array_equal(off, ref_off) and np.array_equal(w, ref_w), (taps, eimpl)
         ref_y = O.decode_batch(ref_w, ref_off, 5000, opts)
         for impl in (0, 7, 8):  # simple kernel; staged kernel (taken when taps[0] = +-1 and <= 4 taps), walk separate / fused
             ctx.set_option("decode_impl", impl)

@@ -42,6 +42,7 @@ struct Geom {
                    //   decode:   1 skip the output stores        2 skip the stream loads
                    //             4 request pieces without counting on the round's minimum consumption
                    //             8 walk with vector loads, 64 chunks per wave (the pre-scalar-load walk)
+                   //           256 never take the workgroup-per-waveform decoder of few long waveforms
                    //   encode:  16 per-code LDS emission instead of the lane-local concatenation
                    //            32 no emission   64 no copy-out   128 no look-back (positions wrong)
     // ragged batches, walk inside the decode launch: chunk indices, short-waveform chunks first

@@ -1150,6 +1150,144 @@ __global__ __launch_bounds__(64) void k_decode_simple(Geom G, const uint32_t *__
     }
 }
 
+// Decoder for FEW, LONG waveforms (WaveformLength = -1, the reference's default, makes every chunk one
+// waveform of millions of samples): one WORKGROUP of 8 wavefronts per waveform, its 512 lanes parse 512
+// consecutive 512-bit segments of the stream at once.  A lane does not know where the first code of its segment
+// starts; it assumes the segment start, parses to the end of its segment and reports where its last
+// code ended.  Rice codes re-synchronise within a few codes, so that end is almost always right even
+// when the start was not.  Each lane then restarts from its predecessor's end until no start changes
+// (lane 0's start is known, so after at most 512 rounds every lane is exact; typically one restart),
+// the sample counts and delta sums of the segments are prefix-summed over the workgroup, and a last parse
+// writes the samples.  Three parses of every bit instead of one, 512 at a time.  Delta filter only (the
+// prefix sum over segment sums is what makes the segments independent).
+constexpr int kLongSeg = 16;  // words per lane and block
+constexpr int kLongOv = 2;    // words of the next segment kept below a lane's column (a code has <= 25 bits)
+constexpr uint32_t kLongSegBits = kLongSeg * 32u;
+// launch_decode() takes this path for uniform batches whose lane-per-waveform decode would leave most of the
+// 98 304 lane slots empty: at most 16 384 waveforms of at least 65 536 samples, or at most 4 096 of at least
+// 16 384 (measured crossover at 350 M samples: L = 32 768 lanes 2.2 ms / long 2.9 ms, L = 65 536 3.6 / 2.4 ms)
+__host__ __device__ inline bool long_waveform_batch(uint64_t total_waves, uint32_t wave_len) {
+    return (wave_len >= 65536u && total_waves <= 16384u) || (wave_len >= 16384u && total_waves <= 4096u);
+}
+
+constexpr int kLongWaves = 8;                 // wavefronts per waveform
+constexpr int kLongThreads = 64 * kLongWaves;  // segments parsed at once
+
+__global__ __launch_bounds__(kLongThreads) void k_decode_long(Geom G, const uint32_t *__restrict__ in,
+                                                              const uint64_t *__restrict__ wave_off,
+                                                              const uint32_t *__restrict__ wave_words, DevStatus *st,
+                                                              int16_t *__restrict__ out) {
+    constexpr uint32_t NT = kLongThreads;
+    __shared__ uint32_t col[(kLongSeg + kLongOv) * NT];  // [word of the segment][thread]: a lane's bank is its lane number
+    __shared__ uint32_t s_end[NT];
+    __shared__ uint32_t s_tot[2][kLongWaves];
+    const uint32_t tid = threadIdx.x;
+    const int wv = (int)(tid >> 6);
+    const uint64_t g = blockIdx.x;
+    if (g >= G.total_waves) return;
+    const WaveRef r = locate(G, g);
+    const uint32_t *src = in + wave_off[g] + 1;
+    const uint32_t n = wave_words[g];
+    int16_t *y = out + r.sample_off;
+    const uint32_t len = r.len, k = G.k;
+
+    uint32_t blk_word = 0;  // first word of the block
+    uint32_t carry_in = 0;  // bit of thread 0's segment at which the next code starts
+    uint32_t done = 0;      // samples written
+    uint32_t acc_base = 0;  // running sum before the block (mod 2^16)
+    const uint32_t *mycol = col + tid;
+
+    // parses this thread's segment from bit `start`; a code is taken when it STARTS inside the segment and inside
+    // the stream.  emit: add to the running sum `acc` and store sample number idx, idx + 1, ...
+    auto parse = [&](bool enable, uint32_t start, uint32_t avail_bits, auto emit_tag, uint32_t idx, uint32_t acc,
+                     uint32_t &end, uint32_t &cnt, uint32_t &sum) __attribute__((always_inline)) {
+        constexpr bool EMIT = decltype(emit_tag)::value;
+        uint32_t pos = start, c = 0, s = EMIT ? acc : 0u;
+        const uint32_t lim = avail_bits < kLongSegBits ? avail_bits : kLongSegBits;
+        while (__any(enable && pos < lim)) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {  // one vote per four codes
+                const bool act = enable && pos < lim;
+                const uint32_t w = act ? pos >> 5 : 0u;
+                const uint64_t two = ((uint64_t)mycol[w * NT] << 32) | mycol[(w + 1u) * NT];
+                const uint32_t win = (uint32_t)((two << (pos & 31u)) >> 32);
+                const uint32_t q = win ? (uint32_t)__builtin_clz(win) : 32u;
+                const uint32_t kk = (win < (1u << 24)) ? 16u : k;
+                const uint32_t used = q + kk + 1u;
+                const uint32_t rem = __builtin_amdgcn_ubfe(win, 32u - used, kk);
+                const uint32_t z = (q << kk) + rem;
+                const uint32_t d = (z >> 1) ^ (0u - (z & 1u));
+                if (act) {
+                    s += d;
+                    if (EMIT && idx + c < len) y[idx + c] = (int16_t)(uint16_t)s;
+                    ++c;
+                    pos += used;
+                }
+            }
+        }
+        end = pos;
+        cnt = c;
+        sum = s;
+    };
+
+    while (done < len && blk_word < n) {
+        // the block's words, transposed into per-thread columns; the first kLongOv words of segment s + 1 repeat below column s
+#pragma unroll
+        for (int rr = 0; rr < kLongSeg; ++rr) {
+            const uint32_t j = tid + NT * (uint32_t)rr;
+            const uint32_t wvl = (blk_word + j < n) ? src[blk_word + j] : 0u;
+            const uint32_t sgm = j / kLongSeg, i = j % kLongSeg;
+            col[i * NT + sgm] = wvl;
+            if (i < (uint32_t)kLongOv && sgm >= 1u) col[((uint32_t)kLongSeg + i) * NT + sgm - 1u] = wvl;
+        }
+        if (tid < (uint32_t)kLongOv) {
+            const uint32_t wi = blk_word + NT * kLongSeg + tid;
+            col[((uint32_t)kLongSeg + tid) * NT + NT - 1u] = (wi < n) ? src[wi] : 0u;
+        }
+        __syncthreads();
+        const uint32_t seg_word = blk_word + tid * kLongSeg;
+        const uint32_t avail_bits = seg_word < n ? ((n - seg_word) > (1u << 26) ? 0xffffffffu : (n - seg_word) * 32u) : 0u;
+
+        uint32_t start = tid == 0 ? carry_in : 0u, end, cnt, sum;
+        parse(true, start, avail_bits, std::false_type{}, 0u, 0u, end, cnt, sum);
+        for (uint32_t it = 0; it < NT; ++it) {
+            s_end[tid] = end;
+            __syncthreads();
+            // where the predecessor's last code ended, as a bit of MY segment (kLongSegBits = "nothing left for me")
+            const uint32_t pe = tid ? s_end[tid - 1u] : 0u;
+            const uint32_t ns = tid == 0 ? carry_in : (pe >= kLongSegBits ? pe - kLongSegBits : kLongSegBits);
+            const bool changed = ns != start;
+            if (!__syncthreads_or(changed ? 1 : 0)) break;  // (also orders the reads of s_end before its next writes)
+            start = ns;
+            uint32_t e2, c2, s2;
+            parse(changed, start, avail_bits, std::false_type{}, 0u, 0u, e2, c2, s2);
+            if (changed) { end = e2; cnt = c2; sum = s2; }
+        }
+        // prefix sums over the workgroup: samples before my segment, sum of deltas before my segment
+        const uint32_t incl_c = wave_incl_scan_dpp(cnt), incl_s = wave_incl_scan_dpp(sum);
+        if ((tid & 63u) == 63u) { s_tot[0][wv] = incl_c; s_tot[1][wv] = incl_s; }
+        s_end[tid] = end;
+        __syncthreads();
+        uint32_t pre_c = 0, pre_s = 0, tot_c = 0, tot_s = 0;
+#pragma unroll
+        for (int i = 0; i < kLongWaves; ++i) {
+            const uint32_t tc = s_tot[0][i], ts = s_tot[1][i];
+            if (i < wv) { pre_c += tc; pre_s += ts; }
+            tot_c += tc;
+            tot_s += ts;
+        }
+        const uint32_t end_last = s_end[NT - 1u];
+        uint32_t e3, c3, s3;
+        parse(true, start, avail_bits, std::true_type{}, done + pre_c + incl_c - cnt, acc_base + pre_s + incl_s - sum, e3, c3, s3);
+        done = (tot_c > len - done) ? len : done + tot_c;
+        acc_base += tot_s;
+        carry_in = end_last >= kLongSegBits ? end_last - kLongSegBits : 0u;
+        blk_word += NT * kLongSeg;
+        __syncthreads();
+    }
+    if (done < len && tid == 0) atomicOr(&st->err, kErrCorrupt);  // the stream ended before the waveform did
+}
+
 // Staged lane-per-waveform decoder (the production kernel; generations 1-4 are in the git
 // history, what each measurement changed is in DESIGN.md).
 //
@@ -1685,9 +1823,11 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
     const bool big_ring = impl == 8 || impl == 15 || impl == 5 || impl == 17;
     const bool needs_block = !G.uniform || G.u_wave_len <= kWalkShortLen;
     // ragged: the group-major grid has max_groups tickets per chunk; not when most of them would be idle
+    // few long waveforms (delta filter): a wavefront per waveform instead of a lane per waveform
+    const bool long_path = !gen && impl != 0 && !(G.dbg & 256u) && G.uniform && long_waveform_batch(G.total_waves, G.u_wave_len);
     const bool sparse = !G.uniform && (uint64_t)G.n_chunks * G.max_groups > 8ull * ((G.total_waves + 63u) / 64u) + 4096ull;
     const bool fused = (impl == 5 || impl == 6 || impl == 8 || impl == 14 || impl == 15 || impl == 17) && (!needs_block || big_ring) &&
-                       !((G.dbg & 8u) && needs_block) && !sparse;  // the in-launch walk needs the arithmetic chunk mapping
+                       !((G.dbg & 8u) && needs_block) && !sparse && !long_path;  // the in-launch walk needs the arithmetic chunk mapping
     if (fused) {
         // granules + ticket word, zeroed before every launch (a granule is its own ready flag)
         hipError_t e = hipMemsetAsync(d_granules, 0, (G.total_waves + 2) * sizeof(uint64_t), s);
@@ -1734,6 +1874,12 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
         }
         mark(ev, 1, s);
         const unsigned nb = blocks_for(G.total_waves, 64);
+        if (long_path) {
+            k_decode_long<<<(unsigned)G.total_waves, kLongThreads, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_status, d_out);
+            mark(ev, 2, s);
+            mark(ev, 3, s);
+            return hipGetLastError();
+        }
         switch (impl) {
             case 0: k_decode_simple<<<nb, 64, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_out); break;
             case 12: k_decode_lanes<32, 16, 64, 8, false, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;

@@ -396,3 +396,45 @@ def test_short_waveform_chunks_walk_through_lds(ctx, O):
         import deltarice_amd as dr
         with pytest.raises(dr.DeltaRiceError):
             plan.decode(dr.EncodedBatch(dev(ctx, bad.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), bad.size))
+
+
+def test_few_long_waveforms_take_the_wave_per_waveform_decoder(ctx, O):
+    """WaveformLength = -1 (the reference's default: the whole chunk is one waveform) and other long waveforms are
+    decoded by a wavefront each with a speculative, self-synchronising parse (k_decode_long).  Noise, a slope-1
+    ramp (a mis-started parse of it never re-synchronises: the worst case, 64 restart rounds), full-range
+    uniform noise (every code an escape), a constant, and a stream cut short."""
+    import deltarice_amd as dr
+    rng = np.random.default_rng(12)
+    n = 300_017
+    cases = {
+        "gauss": rng.normal(0, 10, n).astype(np.int16),
+        "ramp": (np.arange(n) % 60000 - 30000).astype(np.int16),
+        "uniform": rng.integers(-32768, 32768, n).astype(np.int16),
+        "zeros": np.zeros(n, np.int16),
+        "pulses": (rng.normal(0, 3, n) + 8000 * (np.arange(n) % 5000 < 40)).astype(np.int16),
+    }
+    for name, x1 in cases.items():
+        for opts in ((8,), (1,), (16, 100_000), (8, 65536)):
+            x = np.concatenate([x1, x1[::-1], x1])  # three chunks
+            L = opts[1] if len(opts) > 1 else n
+            ref_w, ref_off = O.encode_batch(x, n, opts)
+            plan = ctx.plan_uniform(3, n, (opts[0], L))
+            enc = dr.EncodedBatch(dev(ctx, ref_w.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), ref_w.size)
+            ctx.set_option("debug_flags", 256)  # lane-per-waveform decoder
+            y0 = plan.decode(enc).cpu().numpy()
+            ctx.set_option("debug_flags", 0)    # wave-per-waveform decoder (the default for such batches)
+            y1 = plan.decode(enc).cpu().numpy()
+            assert np.array_equal(y0, x), (name, opts)
+            assert np.array_equal(y1, x), (name, opts)
+            got = plan.encode(dev(ctx, x))
+            w, off = got.to_numpy()
+            assert np.array_equal(off, ref_off) and np.array_equal(w, ref_w), (name, opts)
+    # a stream that ends before its waveform does
+    x = cases["gauss"]
+    w = O.encode_chunk(x, (8,))
+    bad = w.copy()
+    bad[1] -= 5
+    bad = bad[:-5]
+    plan = ctx.plan_uniform(1, n, (8, n))
+    with pytest.raises(dr.DeltaRiceError):
+        plan.decode(dr.EncodedBatch(dev(ctx, bad.view(np.int32)), dev(ctx, np.array([0, bad.size], np.int64)), bad.size))

@@ -15,6 +15,8 @@ import deltarice_amd as dr  # noqa: E402
 def main():
     ctx = dr.Context(0)
     ctx.set_option("profile", 1)
+    if os.environ.get("DRX_DEBUG_FLAGS"):
+        ctx.set_option("debug_flags", int(os.environ["DRX_DEBUG_FLAGS"]))
     lens = [int(a) for a in sys.argv[1:]] or [64, 512, 2048, 3500, 7000, 16384, 65536]
     print(f"{'L':>7s} {'chunks':>6s} {'enc ms':>8s} {'enc GB/s':>9s} {'walk ms':>8s} {'dec ms':>8s} {'dec GB/s':>9s}")
     for L in lens:

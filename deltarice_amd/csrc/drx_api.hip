@@ -57,6 +57,8 @@ struct drx_plan {
     uint64_t *d_chunk_words = nullptr;
     uint64_t *d_scan = nullptr;        // look-back state of the single-pass encoder + ticket
     int32_t *d_taps = nullptr;         // general prediction filter (nullptr: delta)
+    uint32_t *d_seg_bits = nullptr;    // few long waveforms: bits and bit position of every 8192-sample segment,
+    uint64_t *d_seg_pos = nullptr;     // allocated by the first encode that needs them
     uint32_t *d_walk_lists = nullptr;  // ragged plans: chunk indices, short-waveform chunks first
     uint32_t n_short = 0, n_long = 0;
     DevStatus *d_status = nullptr;
@@ -210,6 +212,8 @@ static void plan_free(drx_plan *p) {
     if (p->d_scan) (void)hipFree(p->d_scan);
     if (p->d_taps) (void)hipFree(p->d_taps);
     if (p->d_walk_lists) (void)hipFree(p->d_walk_lists);
+    if (p->d_seg_bits) (void)hipFree(p->d_seg_bits);
+    if (p->d_seg_pos) (void)hipFree(p->d_seg_pos);
     if (p->d_status) (void)hipFree(p->d_status);
     if (p->h_status) (void)hipHostFree(p->h_status);
     for (hipEvent_t e : p->ev) if (e) (void)hipEventDestroy(e);
@@ -375,7 +379,17 @@ drx_status drx_encode(drx_plan *p, const int16_t *d_in, uint32_t *d_out, uint64_
     drx_ctx *ctx = p->ctx;
     DRX_HIP(ctx, hipSetDevice(ctx->device));
     DRX_HIP(ctx, hipMemsetAsync(p->d_status, 0, sizeof(DevStatus), ctx->stream));
-    if (ctx->encode_impl == 1 && (p->G.n_taps == 0 || p->G.enc_fast))
+    p->G.dbg = ctx->debug_flags;
+    if (ctx->encode_impl == 1 && long_batch(p->G) && !(ctx->debug_flags & 256u)) {
+        if (!p->d_seg_bits) {
+            const uint64_t units = p->G.total_waves * long_batch_segments(p->G);
+            DRX_HIP(ctx, hipMalloc((void **)&p->d_seg_bits, units * sizeof(uint32_t)));
+            DRX_HIP(ctx, hipMalloc((void **)&p->d_seg_pos, units * sizeof(uint64_t)));
+        }
+        DRX_HIP(ctx, launch_encode_long(p->G, d_in, d_out, out_cap_words, d_chunk_word_off, p->d_wave_words, p->d_wave_rel,
+                                        p->d_chunk_words, p->d_seg_bits, p->d_seg_pos, p->d_status,
+                                        ctx->profile ? p->ev : nullptr, ctx->stream));
+    } else if (ctx->encode_impl == 1 && (p->G.n_taps == 0 || p->G.enc_fast))
         DRX_HIP(ctx, launch_encode_fused(p->G, d_in, d_out, out_cap_words, d_chunk_word_off, p->d_wave_words,
                                          p->d_scan, p->d_status, ctx->profile ? p->ev : nullptr, ctx->stream));
     else

@@ -71,6 +71,14 @@ hipError_t launch_encode_fused(const Geom &G, const int16_t *d_in, uint32_t *d_o
                                uint64_t *d_chunk_word_off, uint32_t *d_wave_words, uint64_t *d_scan,
                                DevStatus *d_status, hipEvent_t *ev, hipStream_t s);
 
+// few long waveforms (WaveformLength = -1): a wavefront per 8192-sample segment, see drx_kernels.hip
+bool long_batch(const Geom &G);
+uint32_t long_batch_segments(const Geom &G);
+hipError_t launch_encode_long(const Geom &G, const int16_t *d_in, uint32_t *d_out, uint64_t out_cap,
+                              uint64_t *d_chunk_word_off, uint32_t *d_wave_words, uint32_t *d_wave_rel,
+                              uint64_t *d_chunk_words, uint32_t *d_seg_bits, uint64_t *d_seg_pos, DevStatus *d_status,
+                              hipEvent_t *ev, hipStream_t s);
+
 hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                          const uint64_t *d_chunk_word_off, int16_t *d_out, uint64_t *d_wave_off,
                          uint32_t *d_wave_words, uint64_t *d_granules, DevStatus *d_status, int impl,

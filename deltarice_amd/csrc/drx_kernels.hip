@@ -813,6 +813,170 @@ __global__ __launch_bounds__(64 * kEncWaves) void k_encode_fused(Geom G, const i
 }
 
 // ---------------------------------------------------------------------------
+// encode, few long waveforms: a wavefront per SEGMENT of a waveform
+// ---------------------------------------------------------------------------
+// The single-pass encoder gives a waveform to one wavefront; with WaveformLength = -1 (the reference's
+// default) a chunk is one waveform of millions of samples and 25 chunks keep 25 wavefronts busy.  For
+// batches that long_waveform_batch() selects, a waveform is cut into segments of kSegSamples samples:
+//   k_seg_sizes    bits of every segment (the packed tile code of the single-pass encoder, no emission);
+//   k_seg_scan     per waveform: bit position of every segment, n_i;  then k_chunk_scan / k_chunk_offsets;
+//   k_seg_zero     zero the words that two segments share;
+//   k_seg_pack     every segment encoded again, streamed tile by tile through a small LDS stage to its final
+//                  BIT position; words shared with a neighbour are merged with an atomic OR.
+constexpr uint32_t kSegSamples = 16u * kTile;  // 8192 samples per wavefront
+
+struct SegRef {
+    WaveRef r;
+    uint64_t g;       // waveform
+    uint32_t s;       // segment of the waveform
+    uint32_t start;   // first sample of the segment inside the waveform
+    uint32_t count;   // samples in the segment (0: this unit does not exist)
+    bool last;        // last segment of its waveform
+};
+
+__device__ __forceinline__ SegRef locate_seg(const Geom &G, uint64_t u, uint32_t segs_per_wave) {
+    SegRef q;
+    q.g = u / segs_per_wave;
+    q.s = (uint32_t)(u - q.g * segs_per_wave);
+    q.r = locate(G, q.g);
+    q.start = q.s * kSegSamples;
+    q.count = q.start < q.r.len ? ((q.r.len - q.start) < kSegSamples ? (q.r.len - q.start) : kSegSamples) : 0u;
+    q.last = q.start + q.count == q.r.len;
+    return q;
+}
+
+// the tiles of one segment: calls tile(c, lane_bits, incl, tile_bits, full) for each
+template <typename F>
+__device__ __forceinline__ void for_segment_tiles(const int16_t *__restrict__ xw, const SegRef &q, uint32_t k, int lane, F &&tile) {
+    const int16_t *x = xw + q.start;
+    const bool vec_ok = ((uintptr_t)x & 15u) == 0;
+    // dword whose high half is the sample before the segment (x[-1] := 0 at the start of the waveform, :53-54)
+    uint32_t carry = q.start ? ((uint32_t)(uint16_t)xw[q.start - 1u] << 16) : 0u;
+    const u16x2 tp[4] = {splat(1u), splat(0xffffu), splat(0u), splat(0u)};
+    for (uint32_t t0 = 0; t0 < q.count; t0 += kTile) {
+        uint32_t w[4];
+        const int nv = load8_dwords(x, q.count, t0, lane, vec_ok, w);
+        uint32_t xprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[3], 0x138, 0xf, 0xf, false);  // wave_shr:1
+        if (lane == 0) xprev = carry;
+        carry = (uint32_t)__builtin_amdgcn_readlane((int)w[3], 63);
+        PackedCodes c;
+        packed_codes<false>(w, xprev, 0u, tp, k, c);
+        const bool full = t0 + kTile <= q.count;
+        if (!full) mask_tail(c, nv);
+        const uint32_t lane_bits = lane_tile_bits(c);
+        const uint32_t incl = wave_incl_scan_dpp(lane_bits);
+        const uint32_t tile_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        tile(c, lane_bits, incl, tile_bits, full);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_seg_sizes(Geom G, const int16_t *__restrict__ in, uint32_t segs_per_wave,
+                                                   uint64_t n_units, uint32_t *__restrict__ seg_bits) {
+    const int lane = lane_id();
+    const uint64_t u = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (u >= n_units) return;
+    const SegRef q = locate_seg(G, u, segs_per_wave);
+    uint32_t bits = 0;  // <= 8192 * 25
+    for_segment_tiles(in + q.r.sample_off, q, G.k, lane,
+                      [&](const PackedCodes &, uint32_t, uint32_t, uint32_t tile_bits, bool) { bits += tile_bits; });
+    if (lane == 0) seg_bits[u] = bits;
+}
+
+// one wavefront per waveform: exclusive prefix of its segments' bits (a waveform has < 2^31 * 25 / 2^32 ... bits
+// fit 64, positions inside one waveform are kept in 64 bits), n_i
+__global__ __launch_bounds__(64) void k_seg_scan(uint64_t total_waves, uint32_t segs_per_wave, const uint32_t *__restrict__ seg_bits,
+                                                 uint64_t *__restrict__ seg_pos, uint32_t *__restrict__ wave_words) {
+    const int lane = lane_id();
+    const uint64_t g = blockIdx.x;
+    if (g >= total_waves) return;
+    uint64_t run = 0;
+    for (uint32_t s0 = 0; s0 < segs_per_wave; s0 += 64) {
+        const uint32_t sidx = s0 + (uint32_t)lane;
+        const uint32_t v = sidx < segs_per_wave ? seg_bits[g * segs_per_wave + sidx] : 0u;
+        const uint32_t inc = wave_incl_scan_dpp(v);  // 64 * 204 800 bits fit 32
+        if (sidx < segs_per_wave) seg_pos[g * segs_per_wave + sidx] = run + inc - v;
+        run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    }
+    if (lane == 0) wave_words[g] = (uint32_t)((run + 31u) >> 5);
+}
+
+__global__ __launch_bounds__(256) void k_seg_zero(Geom G, uint32_t segs_per_wave, uint64_t n_units,
+                                                  const uint64_t *__restrict__ seg_pos, const uint32_t *__restrict__ wave_rel,
+                                                  const uint64_t *__restrict__ chunk_word_off, uint32_t *__restrict__ out,
+                                                  uint64_t out_cap) {
+    const uint64_t u = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (u >= n_units) return;
+    const SegRef q = locate_seg(G, u, segs_per_wave);
+    if (q.count == 0 || q.s == 0) return;
+    const uint64_t B = seg_pos[u];
+    if ((B & 31u) == 0) return;  // the segment starts on a word boundary: nothing is shared
+    const uint64_t w = chunk_word_off[q.r.chunk] + wave_rel[q.g] + 1u + (B >> 5);
+    if (w < out_cap) out[w] = 0u;
+}
+
+__global__ __launch_bounds__(256) void k_seg_pack(Geom G, const int16_t *__restrict__ in, uint32_t segs_per_wave,
+                                                  uint64_t n_units, const uint64_t *__restrict__ seg_pos,
+                                                  const uint32_t *__restrict__ wave_words, const uint32_t *__restrict__ wave_rel,
+                                                  const uint64_t *__restrict__ chunk_word_off, uint32_t *__restrict__ out,
+                                                  uint64_t out_cap) {
+    // per wave: 4 pad words (place_words ORs zeros below a lane's first word), the stage, slack
+    __shared__ __attribute__((aligned(16))) uint32_t stage_all[4][4 + kStageWords + 12];
+    const int lane = lane_id();
+    uint32_t *row = stage_all[threadIdx.x >> 6];
+    uint32_t *stage = row + 4;
+    const uint64_t u = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (u >= n_units) return;
+    const SegRef q = locate_seg(G, u, segs_per_wave);
+    if (q.count == 0) return;
+    for (int i = lane; i < 4 + (int)kStageWords + 12; i += 64) row[i] = 0;
+    const uint64_t pos = chunk_word_off[q.r.chunk] + wave_rel[q.g];  // the waveform's header word
+    const uint32_t n = wave_words[q.g];
+    if (pos + 1u + n > out_cap) return;  // k_chunk_offsets has raised kErrCapacity
+    if (q.s == 0 && lane == 0) {
+        out[pos] = n;                                    // :379
+        if (q.r.idx == 0) out[pos - 1] = q.r.n_samples;  // chunk header, :415
+    }
+    const uint64_t B = seg_pos[u];
+    uint32_t *__restrict__ outp = out + pos + 1 + (B >> 5);  // the word that holds the segment's first bit
+    const uint32_t stage_bits = lds_addr(stage) * 8u;
+    uint32_t P = (uint32_t)(B & 31u);  // bits in the stage, counted from the start of outp[wdone]
+    uint32_t wdone = 0;                // words of outp already written
+    bool shared_first = (B & 31u) != 0;  // outp[0] also holds the end of the previous segment
+    wave_sync();
+    for_segment_tiles(in + q.r.sample_off, q, G.k, lane,
+                      [&](const PackedCodes &c, uint32_t lane_bits, uint32_t incl, uint32_t tile_bits, bool full) {
+        if (full && !__any(lane_bits > 128u)) {
+            uint32_t cw[4];
+            concat_codes(c, cw);
+            place_words(cw, stage_bits + P + incl);
+        } else {
+            emit_tile<false>(c, stage_bits + P + incl - lane_bits);
+        }
+        P += tile_bits;
+        wave_sync();
+        const uint32_t nfull = P >> 5;
+        for (uint32_t i = lane; i < nfull; i += 64) {
+            const uint32_t v = stage[i];
+            stage[i] = 0;
+            if (i == 0 && shared_first) atomicOr(outp + wdone, v); else outp[wdone + i] = v;
+        }
+        wave_sync();
+        if (nfull) {
+            if (lane == 0) { const uint32_t cwd = stage[nfull]; stage[nfull] = 0; stage[0] = cwd; }
+            shared_first = false;
+            wdone += nfull;
+            P &= 31u;
+        }
+        wave_sync();
+    });
+    if (P && lane == 0) {
+        // the last, partly filled word: the next segment continues in it, unless the waveform ends here
+        // (then it is left aligned and zero padded, :237-241)
+        if (q.last && !shared_first) outp[wdone] = stage[0]; else atomicOr(outp + wdone, stage[0]);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // decode
 // ---------------------------------------------------------------------------
 
@@ -1797,6 +1961,31 @@ hipError_t launch_encode(const Geom &G, const int16_t *d_in, uint32_t *d_out, ui
     mark(ev, 2, s);
     k_encode_pack<<<blocks_for(G.total_waves, 4), 256, 0, s>>>(G, d_in, d_wave_words, d_wave_rel,
                                                                d_chunk_word_off, d_out, out_cap);
+    mark(ev, 3, s);
+    return hipGetLastError();
+}
+
+bool long_batch(const Geom &G) { return G.uniform && G.n_taps == 0 && long_waveform_batch(G.total_waves, G.u_wave_len); }
+uint32_t long_batch_segments(const Geom &G) { return (G.u_wave_len + kSegSamples - 1u) / kSegSamples; }
+
+// Encoder for few long waveforms.  d_seg_bits: uint32[total_waves * segments], d_seg_pos: uint64[same].
+hipError_t launch_encode_long(const Geom &G, const int16_t *d_in, uint32_t *d_out, uint64_t out_cap,
+                              uint64_t *d_chunk_word_off, uint32_t *d_wave_words, uint32_t *d_wave_rel,
+                              uint64_t *d_chunk_words, uint32_t *d_seg_bits, uint64_t *d_seg_pos, DevStatus *d_status,
+                              hipEvent_t *ev, hipStream_t s) {
+    if (G.total_waves == 0) return hipSuccess;
+    const uint32_t S = long_batch_segments(G);
+    const uint64_t units = G.total_waves * S;
+    mark(ev, 0, s);
+    k_seg_sizes<<<blocks_for(units, 4), 256, 0, s>>>(G, d_in, S, units, d_seg_bits);
+    mark(ev, 1, s);
+    k_seg_scan<<<(unsigned)G.total_waves, 64, 0, s>>>(G.total_waves, S, d_seg_bits, d_seg_pos, d_wave_words);
+    k_chunk_scan<<<(unsigned)G.n_chunks, 256, 0, s>>>(G, d_wave_words, d_wave_rel, d_chunk_words);
+    k_chunk_offsets<<<1, 1024, 0, s>>>(G.n_chunks, d_chunk_words, d_chunk_word_off, out_cap, d_status);
+    k_seg_zero<<<blocks_for(units, 256), 256, 0, s>>>(G, S, units, d_seg_pos, d_wave_rel, d_chunk_word_off, d_out, out_cap);
+    mark(ev, 2, s);
+    k_seg_pack<<<blocks_for(units, 4), 256, 0, s>>>(G, d_in, S, units, d_seg_pos, d_wave_words, d_wave_rel, d_chunk_word_off,
+                                                    d_out, out_cap);
     mark(ev, 3, s);
     return hipGetLastError();
 }

@@ -59,6 +59,7 @@ struct drx_plan {
     int32_t *d_taps = nullptr;         // general prediction filter (nullptr: delta)
     uint32_t *d_seg_bits = nullptr;    // few long waveforms: bits and bit position of every 8192-sample segment,
     uint64_t *d_seg_pos = nullptr;     // allocated by the first encode that needs them
+    uint64_t *d_long = nullptr;        // a handful of long waveforms: scratch of the workgroup-per-block decoder
     uint32_t *d_walk_lists = nullptr;  // ragged plans: chunk indices, short-waveform chunks first
     uint32_t n_short = 0, n_long = 0;
     DevStatus *d_status = nullptr;
@@ -214,6 +215,7 @@ static void plan_free(drx_plan *p) {
     if (p->d_walk_lists) (void)hipFree(p->d_walk_lists);
     if (p->d_seg_bits) (void)hipFree(p->d_seg_bits);
     if (p->d_seg_pos) (void)hipFree(p->d_seg_pos);
+    if (p->d_long) (void)hipFree(p->d_long);
     if (p->d_status) (void)hipFree(p->d_status);
     if (p->h_status) (void)hipHostFree(p->h_status);
     for (hipEvent_t e : p->ev) if (e) (void)hipEventDestroy(e);
@@ -408,9 +410,13 @@ static drx_status decode_launch(drx_plan *p, const uint32_t *d_in, uint64_t in_w
     DRX_HIP(ctx, hipSetDevice(ctx->device));
     DRX_HIP(ctx, hipMemsetAsync(p->d_status, 0, sizeof(DevStatus), ctx->stream));
     p->G.dbg = ctx->debug_flags;
+    if (!p->d_long) {
+        const uint64_t nb = long_decode_scratch_bytes(p->G);
+        if (nb) DRX_HIP(ctx, hipMalloc((void **)&p->d_long, nb));
+    }
     DRX_HIP(ctx, launch_decode(p->G, d_in, in_words, d_chunk_word_off, d_out, p->d_wave_off,
                                p->d_wave_words, p->d_scan, p->d_status,
-                               (tables_ready ? 100 : 0) + ctx->decode_impl,
+                               (tables_ready ? 100 : 0) + ctx->decode_impl, p->d_long,
                                ctx->profile ? p->ev : nullptr, ctx->stream));
     p->ev_valid = ctx->profile != 0;
     p->last_was_encode = false;

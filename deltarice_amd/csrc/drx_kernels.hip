@@ -1334,29 +1334,57 @@ __host__ __device__ inline bool long_waveform_batch(uint64_t total_waves, uint32
     return (wave_len >= 65536u && total_waves <= 16384u) || (wave_len >= 16384u && total_waves <= 4096u);
 }
 
-constexpr int kLongWaves = 8;                 // wavefronts per waveform
+constexpr int kLongWaves = 8;                 // wavefronts per workgroup
 constexpr int kLongThreads = 64 * kLongWaves;  // segments parsed at once
+constexpr uint32_t kLongBlockWords = kLongThreads * kLongSeg;  // 8192 words of the stream per block
 
+// MULTI = false: one workgroup per waveform walks its blocks in order (fail != nullptr: only the waveforms it flags).
+// MULTI = true (a handful of waveforms: one workgroup each would leave the GPU empty): one workgroup per BLOCK.
+//   The bit at which a block's first code starts is predicted by k_long_tail (a parse of the previous block's
+//   last 64 words from an assumed boundary: it has re-synchronised by the block's end, or the check below fails),
+//   the number of samples and the delta sum in front of a block come from a decoupled look-back over the
+//   blocks of the waveform (tickets, 8-byte {status | count | sum} entries, as in the encoder).  A block whose
+//   real end differs from the prediction its successor used flags the waveform; flagged waveforms are decoded
+//   again by the MULTI = false kernel afterwards.
+template <bool MULTI>
 __global__ __launch_bounds__(kLongThreads) void k_decode_long(Geom G, const uint32_t *__restrict__ in,
                                                               const uint64_t *__restrict__ wave_off,
                                                               const uint32_t *__restrict__ wave_words, DevStatus *st,
-                                                              int16_t *__restrict__ out) {
+                                                              int16_t *__restrict__ out, uint32_t blocks_max,
+                                                              const uint32_t *__restrict__ tail_end,
+                                                              uint64_t *__restrict__ state, uint32_t *__restrict__ ticket,
+                                                              uint32_t *__restrict__ fail) {
     constexpr uint32_t NT = kLongThreads;
     __shared__ uint32_t col[(kLongSeg + kLongOv) * NT];  // [word of the segment][thread]: a lane's bank is its lane number
     __shared__ uint32_t s_end[NT];
     __shared__ uint32_t s_tot[2][kLongWaves];
+    __shared__ uint64_t s_bcast[2];
     const uint32_t tid = threadIdx.x;
-    const int wv = (int)(tid >> 6);
-    const uint64_t g = blockIdx.x;
+    const int wv = (int)(tid >> 6), lane = (int)(tid & 63u);
+    uint64_t g, unit = 0;
+    uint32_t blk = 0;
+    if (MULTI) {
+        if (tid == 0) s_bcast[0] = atomicAdd(ticket, 1u);
+        __syncthreads();
+        unit = s_bcast[0];
+        __syncthreads();
+        g = unit / blocks_max;
+        blk = (uint32_t)(unit - g * blocks_max);
+    } else {
+        g = blockIdx.x;
+    }
     if (g >= G.total_waves) return;
+    if (!MULTI && fail && !fail[g]) return;
     const WaveRef r = locate(G, g);
     const uint32_t *src = in + wave_off[g] + 1;
     const uint32_t n = wave_words[g];
     int16_t *y = out + r.sample_off;
     const uint32_t len = r.len, k = G.k;
+    const uint32_t n_blocks = (n + kLongBlockWords - 1u) / kLongBlockWords;
+    if (MULTI && blk >= n_blocks) return;
 
-    uint32_t blk_word = 0;  // first word of the block
-    uint32_t carry_in = 0;  // bit of thread 0's segment at which the next code starts
+    uint32_t blk_word = MULTI ? blk * kLongBlockWords : 0u;  // first word of the block
+    uint32_t carry_in = (MULTI && blk) ? tail_end[unit - 1u] : 0u;  // bit of thread 0's segment at which the next code starts
     uint32_t done = 0;      // samples written
     uint32_t acc_base = 0;  // running sum before the block (mod 2^16)
     const uint32_t *mycol = col + tid;
@@ -1366,7 +1394,7 @@ __global__ __launch_bounds__(kLongThreads) void k_decode_long(Geom G, const uint
     auto parse = [&](bool enable, uint32_t start, uint32_t avail_bits, auto emit_tag, uint32_t idx, uint32_t acc,
                      uint32_t &end, uint32_t &cnt, uint32_t &sum) __attribute__((always_inline)) {
         constexpr bool EMIT = decltype(emit_tag)::value;
-        uint32_t pos = start, c = 0, s = EMIT ? acc : 0u;
+        uint32_t pos = start, c = 0, sacc = EMIT ? acc : 0u;
         const uint32_t lim = avail_bits < kLongSegBits ? avail_bits : kLongSegBits;
         while (__any(enable && pos < lim)) {
 #pragma unroll
@@ -1382,8 +1410,8 @@ __global__ __launch_bounds__(kLongThreads) void k_decode_long(Geom G, const uint
                 const uint32_t z = (q << kk) + rem;
                 const uint32_t d = (z >> 1) ^ (0u - (z & 1u));
                 if (act) {
-                    s += d;
-                    if (EMIT && idx + c < len) y[idx + c] = (int16_t)(uint16_t)s;
+                    sacc += d;
+                    if (EMIT && idx + c < len) y[idx + c] = (int16_t)(uint16_t)sacc;
                     ++c;
                     pos += used;
                 }
@@ -1391,7 +1419,7 @@ __global__ __launch_bounds__(kLongThreads) void k_decode_long(Geom G, const uint
         }
         end = pos;
         cnt = c;
-        sum = s;
+        sum = sacc;
     };
 
     while (done < len && blk_word < n) {
@@ -1429,7 +1457,7 @@ __global__ __launch_bounds__(kLongThreads) void k_decode_long(Geom G, const uint
         }
         // prefix sums over the workgroup: samples before my segment, sum of deltas before my segment
         const uint32_t incl_c = wave_incl_scan_dpp(cnt), incl_s = wave_incl_scan_dpp(sum);
-        if ((tid & 63u) == 63u) { s_tot[0][wv] = incl_c; s_tot[1][wv] = incl_s; }
+        if (lane == 63) { s_tot[0][wv] = incl_c; s_tot[1][wv] = incl_s; }
         s_end[tid] = end;
         __syncthreads();
         uint32_t pre_c = 0, pre_s = 0, tot_c = 0, tot_s = 0;
@@ -1441,15 +1469,89 @@ __global__ __launch_bounds__(kLongThreads) void k_decode_long(Geom G, const uint
             tot_s += ts;
         }
         const uint32_t end_last = s_end[NT - 1u];
+        if (MULTI) {
+            // samples / delta sum in front of this block: look back over the blocks of the waveform
+            if (wv == 0) {
+                const uint64_t mine = ((uint64_t)tot_c << 16) | (uint64_t)(tot_s & 0xffffu);
+                uint64_t ex_c = 0, ex_s = 0;
+                if (blk == 0) {
+                    if (lane == 0) __hip_atomic_store(state + unit, kScanPrefix | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    if (lane == 0) __hip_atomic_store(state + unit, kScanAgg | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int64_t first = (int64_t)(unit - blk);  // block 0 of this waveform
+                    int64_t base = (int64_t)unit - 1;
+                    uint32_t spins = 0;
+                    for (;;) {
+                        const int64_t i0 = base - lane;
+                        uint64_t sv = kScanPrefix;  // in front of block 0: an empty prefix
+                        if (i0 >= first) sv = __hip_atomic_load(state + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint32_t stt = (uint32_t)(sv >> 62);
+                        const uint64_t pm = __ballot(stt == 2u), zm = __ballot(stt == 0u);
+                        const int fp = pm ? __builtin_ctzll(pm) : 64;
+                        const uint64_t nearer = fp >= 64 ? ~0ull : ((1ull << fp) - 1ull);
+                        if (zm & nearer) {
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++spins > (1u << 22)) { if (lane == 0) atomicOr(&st->err, kErrInternal); break; }
+                            continue;
+                        }
+                        const uint64_t val = (lane <= fp) ? (sv & kScanValMask) : 0ull;
+                        ex_c += wave_sum_u64(val >> 16);
+                        ex_s += wave_sum_u64(val & 0xffffull);
+                        if (fp < 64) break;
+                        base -= 64;
+                    }
+                    if (lane == 0)
+                        __hip_atomic_store(state + unit, kScanPrefix | ((((ex_c + tot_c) << 16) | ((ex_s + tot_s) & 0xffffull)) & kScanValMask),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (lane == 0) { s_bcast[0] = ex_c; s_bcast[1] = ex_s; }
+            }
+            __syncthreads();
+            done = (uint32_t)(s_bcast[0] > (uint64_t)len ? (uint64_t)len : s_bcast[0]);
+            acc_base = (uint32_t)s_bcast[1];
+            // the successor started from the predicted end of this block
+            if (tid == 0 && blk + 1u < n_blocks) {
+                const uint32_t real = end_last >= kLongSegBits ? end_last - kLongSegBits : 0u;
+                if (real != tail_end[unit]) atomicExch(fail + g, 1u);
+            }
+        }
         uint32_t e3, c3, s3;
         parse(true, start, avail_bits, std::true_type{}, done + pre_c + incl_c - cnt, acc_base + pre_s + incl_s - sum, e3, c3, s3);
         done = (tot_c > len - done) ? len : done + tot_c;
+        if (MULTI) {
+            if (blk + 1u == n_blocks && done < len && tid == 0) atomicOr(&st->err, kErrCorrupt);
+            return;
+        }
         acc_base += tot_s;
         carry_in = end_last >= kLongSegBits ? end_last - kLongSegBits : 0u;
         blk_word += NT * kLongSeg;
         __syncthreads();
     }
-    if (done < len && tid == 0) atomicOr(&st->err, kErrCorrupt);  // the stream ended before the waveform did
+    if (!MULTI && done < len && tid == 0) atomicOr(&st->err, kErrCorrupt);  // the stream ended before the waveform did
+}
+
+// MULTI: where block b + 1's first code starts, predicted by one lane per block from the last 64 words of block b
+__global__ __launch_bounds__(64) void k_long_tail(Geom G, const uint32_t *__restrict__ in, const uint64_t *__restrict__ wave_off,
+                                                  const uint32_t *__restrict__ wave_words, uint32_t blocks_max,
+                                                  uint32_t *__restrict__ tail_end) {
+    const uint64_t unit = (uint64_t)blockIdx.x * 64u + threadIdx.x;
+    const uint64_t g = unit / blocks_max;
+    if (g >= G.total_waves) return;
+    const uint32_t blk = (uint32_t)(unit - g * blocks_max);
+    const uint32_t n = wave_words[g];
+    const uint32_t n_blocks = (n + kLongBlockWords - 1u) / kLongBlockWords;
+    if (blk + 1u >= n_blocks) return;  // the last block has no successor
+    const uint32_t *src = in + wave_off[g] + 1;
+    const uint32_t w0 = (blk + 1u) * kLongBlockWords - 64u, k = G.k;
+    uint32_t pos = 0;
+    while (pos < 64u * 32u) {
+        const uint32_t w = w0 + (pos >> 5);
+        const uint64_t two = ((uint64_t)(w < n ? src[w] : 0u) << 32) | (w + 1u < n ? src[w + 1u] : 0u);
+        const uint32_t win = (uint32_t)((two << (pos & 31u)) >> 32);
+        const uint32_t q = win ? (uint32_t)__builtin_clz(win) : 32u;
+        pos += q + ((win < (1u << 24)) ? 16u : k) + 1u;
+    }
+    tail_end[unit] = pos - 64u * 32u;
 }
 
 // Staged lane-per-waveform decoder (the production kernel; generations 1-4 are in the git
@@ -1965,6 +2067,18 @@ hipError_t launch_encode(const Geom &G, const int16_t *d_in, uint32_t *d_out, ui
     return hipGetLastError();
 }
 
+// workgroup-per-block decode of a handful of long waveforms
+constexpr uint64_t kLongMultiMaxWaves = 256;
+uint32_t long_decode_blocks_max(const Geom &G) {  // 25 bits per sample at worst
+    const uint64_t max_words = ((uint64_t)G.u_wave_len * 25u + 31u) >> 5;
+    return (uint32_t)((max_words + kLongBlockWords - 1u) / kLongBlockWords);
+}
+uint64_t long_decode_scratch_bytes(const Geom &G) {
+    if (!(G.uniform && G.n_taps == 0 && long_waveform_batch(G.total_waves, G.u_wave_len)) || G.total_waves > kLongMultiMaxWaves) return 0;
+    const uint64_t units = G.total_waves * long_decode_blocks_max(G);
+    return units * 12u + (G.total_waves + 2u) * 4u;
+}
+
 bool long_batch(const Geom &G) { return G.uniform && G.n_taps == 0 && long_waveform_batch(G.total_waves, G.u_wave_len); }
 uint32_t long_batch_segments(const Geom &G) { return (G.u_wave_len + kSegSamples - 1u) / kSegSamples; }
 
@@ -1993,7 +2107,7 @@ hipError_t launch_encode_long(const Geom &G, const int16_t *d_in, uint32_t *d_ou
 hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                          const uint64_t *d_chunk_word_off, int16_t *d_out, uint64_t *d_wave_off,
                          uint32_t *d_wave_words, uint64_t *d_granules, DevStatus *d_status, int impl,
-                         hipEvent_t *ev, hipStream_t s) {
+                         uint64_t *d_long, hipEvent_t *ev, hipStream_t s) {
     if (G.total_waves == 0) return hipSuccess;
     mark(ev, 0, s);
     // impl >= 100: wave_off / wave_words are already filled in (the one-chunk host path walks the header
@@ -2064,7 +2178,24 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
         mark(ev, 1, s);
         const unsigned nb = blocks_for(G.total_waves, 64);
         if (long_path) {
-            k_decode_long<<<(unsigned)G.total_waves, kLongThreads, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_status, d_out);
+            const uint32_t blocks_max = long_decode_blocks_max(G);
+            const uint64_t units = G.total_waves * blocks_max;
+            if (d_long && G.total_waves <= kLongMultiMaxWaves && !(G.dbg & 512u)) {
+                // scratch: uint64 state[units] | uint32 tail_end[units] | uint32 fail[total_waves] | uint32 ticket
+                uint64_t *state = d_long;
+                uint32_t *tail_end = reinterpret_cast<uint32_t *>(d_long + units);
+                uint32_t *fail = tail_end + units, *tick = fail + G.total_waves;
+                hipError_t e = hipMemsetAsync(d_long, 0, long_decode_scratch_bytes(G), s);
+                if (e != hipSuccess) return e;
+                k_long_tail<<<blocks_for(units, 64), 64, 0, s>>>(G, d_in, d_wave_off, d_wave_words, blocks_max, tail_end);
+                k_decode_long<true><<<(unsigned)units, kLongThreads, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_status, d_out,
+                                                                             blocks_max, tail_end, state, tick, fail);
+                k_decode_long<false><<<(unsigned)G.total_waves, kLongThreads, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_status, d_out,
+                                                                                     0u, nullptr, nullptr, nullptr, fail);
+            } else {
+                k_decode_long<false><<<(unsigned)G.total_waves, kLongThreads, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_status, d_out,
+                                                                                     0u, nullptr, nullptr, nullptr, nullptr);
+            }
             mark(ev, 2, s);
             mark(ev, 3, s);
             return hipGetLastError();

@@ -420,15 +420,13 @@ def test_few_long_waveforms_take_the_wave_per_waveform_decoder(ctx, O):
             ref_w, ref_off = O.encode_batch(x, n, opts)
             plan = ctx.plan_uniform(3, n, (opts[0], L))
             enc = dr.EncodedBatch(dev(ctx, ref_w.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), ref_w.size)
-            ctx.set_option("debug_flags", 256)  # lane-per-waveform decoder
-            y0 = plan.decode(enc).cpu().numpy()
-            ctx.set_option("debug_flags", 0)    # wave-per-waveform decoder (the default for such batches)
-            y1 = plan.decode(enc).cpu().numpy()
-            assert np.array_equal(y0, x), (name, opts)
-            assert np.array_equal(y1, x), (name, opts)
-            got = plan.encode(dev(ctx, x))
-            w, off = got.to_numpy()
-            assert np.array_equal(off, ref_off) and np.array_equal(w, ref_w), (name, opts)
+            # 256: lane-per-waveform decoder / single-pass encoder; 512: one workgroup per waveform;
+            # 0: the defaults for such batches (a workgroup per block, a wavefront per 8192-sample segment)
+            for flags in (256, 512, 0):
+                ctx.set_option("debug_flags", flags)
+                assert np.array_equal(plan.decode(enc).cpu().numpy(), x), (name, opts, flags)
+                w, off = plan.encode(dev(ctx, x)).to_numpy()
+                assert np.array_equal(off, ref_off) and np.array_equal(w, ref_w), (name, opts, flags)
     # a stream that ends before its waveform does
     x = cases["gauss"]
     w = O.encode_chunk(x, (8,))

@@ -1337,6 +1337,7 @@ __host__ __device__ inline bool long_waveform_batch(uint64_t total_waves, uint32
 constexpr int kLongWaves = 8;                 // wavefronts per workgroup
 constexpr int kLongThreads = 64 * kLongWaves;  // segments parsed at once
 constexpr uint32_t kLongBlockWords = kLongThreads * kLongSeg;  // 8192 words of the stream per block
+constexpr uint32_t kLongGuessBits = 160;  // bits in front of a segment's end from which the first guess is parsed
 
 // MULTI = false: one workgroup per waveform walks its blocks in order (fail != nullptr: only the waveforms it flags).
 // MULTI = true (a handful of waveforms: one workgroup each would leave the GPU empty): one workgroup per BLOCK.
@@ -1440,7 +1441,9 @@ __global__ __launch_bounds__(kLongThreads) void k_decode_long(Geom G, const uint
         const uint32_t seg_word = blk_word + tid * kLongSeg;
         const uint32_t avail_bits = seg_word < n ? ((n - seg_word) > (1u << 26) ? 0xffffffffu : (n - seg_word) * 32u) : 0u;
 
-        uint32_t start = tid == 0 ? carry_in : 0u, end, cnt, sum;
+        // first guess: only where the segment's last code ends is wanted, and a parse re-synchronises within a few
+        // codes, so the guess starts kLongGuessBits before the segment's end (thread 0 knows its start)
+        uint32_t start = tid == 0 ? carry_in : kLongSegBits - kLongGuessBits, end, cnt, sum;
         parse(true, start, avail_bits, std::false_type{}, 0u, 0u, end, cnt, sum);
         for (uint32_t it = 0; it < NT; ++it) {
             s_end[tid] = end;

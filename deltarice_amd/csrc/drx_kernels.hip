@@ -2082,7 +2082,13 @@ uint64_t long_decode_scratch_bytes(const Geom &G) {
     return units * 12u + (G.total_waves + 2u) * 4u;
 }
 
-bool long_batch(const Geom &G) { return G.uniform && G.n_taps == 0 && long_waveform_batch(G.total_waves, G.u_wave_len); }
+// Batches the segment encoder takes: few long waveforms, and SHORT waveforms (one segment each), where the
+// single-pass encoder pays a workgroup barrier, a look-back and an 8 KB LDS clear per 512-2048 samples
+// (200 chunks of 14 M samples: L = 512 0.57 -> 0.95 TB/s, 1024 0.97 -> 1.33, 2048 1.51 -> 1.68; 7000 is better off
+// with the single pass)
+bool long_batch(const Geom &G) {
+    return G.uniform && G.n_taps == 0 && (long_waveform_batch(G.total_waves, G.u_wave_len) || G.u_wave_len <= kWalkShortLen);
+}
 uint32_t long_batch_segments(const Geom &G) { return (G.u_wave_len + kSegSamples - 1u) / kSegSamples; }
 
 // Encoder for few long waveforms.  d_seg_bits: uint32[total_waves * segments], d_seg_pos: uint64[same].

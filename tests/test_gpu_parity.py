@@ -30,16 +30,21 @@ def dev(ctx, a):
 
 
 def gpu_encode(ctx, plan, x):
-    """Encodes with both encoder implementations (single pass with look-back, and the
-    size/scan/pack passes), checks they agree, returns the default one's result."""
+    """Encodes with every encoder (the simple size/scan/pack passes; the single pass with look-back, forced
+    with debug flag 256; and whatever the batch shape selects by default, which is the segment encoder for
+    short and for few long waveforms), checks they agree, returns the default one's result."""
     xd = dev(ctx, x.reshape(-1).view(np.int16))
     ctx.set_option("encode_impl", 0)
     enc0 = plan.encode(xd)
     w0, off0 = enc0.to_numpy()
     ctx.set_option("encode_impl", 1)
+    ctx.set_option("debug_flags", 256)
+    w1, off1 = plan.encode(xd).to_numpy()
+    ctx.set_option("debug_flags", 0)
     enc = plan.encode(xd)
     w, off = enc.to_numpy()
     assert np.array_equal(off, off0) and np.array_equal(w, w0), "encoder implementations disagree"
+    assert np.array_equal(off1, off0) and np.array_equal(w1, w0), "single-pass encoder disagrees"
     return enc, w, off
 
 

@@ -21,7 +21,7 @@ def main():
     print(f"{'L':>7s} {'chunks':>6s} {'enc ms':>8s} {'enc GB/s':>9s} {'walk ms':>8s} {'dec ms':>8s} {'dec GB/s':>9s}")
     for L in lens:
         n_w = 14_000_000 // L
-        n_chunks = 25
+        n_chunks = int(os.environ.get("DRX_SWEEP_CHUNKS", 25))
         N = n_w * L
         g = torch.Generator(device=ctx.device).manual_seed(L)
         x = (torch.randn(n_chunks * N, device=ctx.device, generator=g) * 10).to(torch.int16)

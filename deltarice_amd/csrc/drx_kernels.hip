@@ -1540,7 +1540,9 @@ __global__ __launch_bounds__(kLongThreads) void k_decode_long(Geom G, const uint
         parse(true, start, avail_bits, std::true_type{}, done + pre_c + incl_c - cnt, acc_base + pre_s + incl_s - sum, e3, c3, s3);
         done = (tot_c > len - done) ? len : done + tot_c;
         if (MULTI) {
-            if (blk + 1u == n_blocks && done < len && tid == 0) atomicOr(&st->err, kErrCorrupt);
+            // too few samples: a wrong prediction somewhere in front, or a stream that really ends early -- the
+            // one-workgroup kernel decides (it decodes flagged waveforms again and is the one that raises kErrCorrupt)
+            if (blk + 1u == n_blocks && done < len && tid == 0) atomicExch(fail + g, 1u);
             return;
         }
         acc_base += tot_s;

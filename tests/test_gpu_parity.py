@@ -1,6 +1,8 @@
 """GPU parity: the HIP path (through the C ABI) against the oracle and the golden vectors.
 
 Everything here is bit-exact: integer codec, no tolerance."""
+import os
+
 import numpy as np
 import pytest
 
@@ -432,6 +434,13 @@ def test_few_long_waveforms_take_the_wave_per_waveform_decoder(ctx, O):
                 assert np.array_equal(plan.decode(enc).cpu().numpy(), x), (name, opts, flags)
                 w, off = plan.encode(dev(ctx, x)).to_numpy()
                 assert np.array_equal(off, ref_off) and np.array_equal(w, ref_w), (name, opts, flags)
+    # regression: zeros at k = 13 never re-synchronise a mis-started parse either; the block-parallel kernel must
+    # leave the verdict to the fallback (it once raised DRX_ERR_CORRUPT from its garbage counts)
+    z = np.zeros(2 * 600_000, np.int16)
+    ref_w, ref_off = O.encode_batch(z, 600_000, (8192, 65536))
+    plan = ctx.plan_uniform(2, 600_000, (8192, 65536))
+    enc = dr.EncodedBatch(dev(ctx, ref_w.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), ref_w.size)
+    assert np.array_equal(plan.decode(enc).cpu().numpy(), z)
     # a stream that ends before its waveform does
     x = cases["gauss"]
     w = O.encode_chunk(x, (8,))
@@ -441,3 +450,14 @@ def test_few_long_waveforms_take_the_wave_per_waveform_decoder(ctx, O):
     plan = ctx.plan_uniform(1, n, (8, n))
     with pytest.raises(dr.DeltaRiceError):
         plan.decode(dr.EncodedBatch(dev(ctx, bad.view(np.int32)), dev(ctx, np.array([0, bad.size], np.int64)), bad.size))
+
+
+def test_randomised_shapes_vs_oracle():
+    """tools/fuzz_parity.py with a fixed seed: random uniform / ragged batches, WaveformLength from 1 to 300 000,
+    every k, five signal kinds, general filters; every encoder and the decoder variants a shape can take."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "120", "11"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on the GPU: random batch shapes (uniform and ragged), waveform lengths from 1 to
+hundreds of thousands, every k, several signal kinds, general filters; GPU encode must equal the oracle's
+bytes and GPU decode (default path and the variants a shape can take) must return the input.
+usage: tools/fuzz_parity.py [cases] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import deltarice_amd as dr  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def data(rng, kind, n, k):
+    if kind == "gauss":
+        return rng.normal(0, rng.choice([1, 10, 300, 5000]), n).astype(np.int16)
+    if kind == "uniform":
+        return rng.integers(-32768, 32768, n).astype(np.int16)
+    if kind == "zeros":
+        return np.zeros(n, np.int16)
+    if kind == "ramp":
+        return ((np.arange(n) * int(rng.integers(1, 4))) % 60000 - 30000).astype(np.int16)
+    if kind == "pulses":
+        x = rng.normal(0, 3, n)
+        x += 9000 * ((np.arange(n) % int(rng.integers(50, 5000))) < int(rng.integers(1, 40)))
+        return x.astype(np.int16)
+    raise ValueError(kind)
+
+
+def dev(ctx, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(ctx.device)
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    ctx = dr.Context(0)
+    t0 = time.time()
+    for it in range(cases):
+        k = int(rng.integers(1, 16)) if rng.random() < 0.9 else 0
+        kind = str(rng.choice(["gauss", "uniform", "zeros", "ramp", "pulses"]))
+        Lc = [1, 2, 3, 7, 8, 9, 63, 64, 65, 511, 512, 513, 1000, 2047, 2048, 2049, 7000, 8191, 8192, 8193, 16384, 40000,
+              65535, 65536, 65537, 100000, 300000]
+        ragged = rng.random() < 0.25
+        n_chunks = int(rng.integers(1, 6))
+        taps = None
+        if not ragged and rng.random() < 0.2:
+            nt = int(rng.integers(1, 6))
+            taps = [int(rng.choice([1, -1])) if rng.random() < 0.8 else int(rng.integers(2, 5))] + [int(v) for v in rng.integers(-3, 4, nt - 1)]
+        if ragged:
+            Ls = [int(rng.choice(Lc)) for _ in range(n_chunks)]
+            Ns = [int(min(400000, max(1, L * int(rng.integers(1, 40)) + int(rng.integers(0, L))))) for L in Ls]
+        else:
+            L = int(rng.choice(Lc))
+            N = int(min(600000, max(1, L * int(rng.integers(1, 60)) + (int(rng.integers(0, L)) if rng.random() < 0.5 else 0))))
+            Ls, Ns = [L] * n_chunks, [N] * n_chunks
+        if k == 0:
+            kind = "zeros" if kind == "uniform" else kind  # M = 1 is defined only while z < 32768
+        x = np.concatenate([data(rng, kind, n, k) for n in Ns])
+        if k == 0:
+            x = (x // 4).astype(np.int16)
+        label = f"case {it}: k={k} {kind} chunks={n_chunks} L={Ls} N={Ns} taps={taps}"
+        try:
+            # oracle stream, chunk by chunk
+            words, offs = [], [0]
+            pos = 0
+            for n, L in zip(Ns, Ls):
+                opts = (1 << k, L) + ((len(taps),) + tuple(t & 0xFFFFFFFF for t in taps) if taps else ())
+                w = O.encode_chunk(x[pos:pos + n], opts)
+                words.append(w)
+                offs.append(offs[-1] + w.size)
+                pos += n
+            ref_w = np.concatenate(words)
+            ref_off = np.array(offs, np.uint64)
+            if ragged:
+                plan = ctx.plan(Ns, Ls, 1 << k)
+            else:
+                opts = (1 << k, Ls[0]) + ((len(taps),) + tuple(t & 0xFFFFFFFF for t in taps) if taps else ())
+                plan = ctx.plan_uniform(n_chunks, Ns[0], opts)
+            xd = dev(ctx, x)
+            for flags in (0, 256):
+                ctx.set_option("debug_flags", flags)
+                for eimpl in (1, 0):
+                    ctx.set_option("encode_impl", eimpl)
+                    w, off = plan.encode(xd).to_numpy()
+                    assert np.array_equal(off, ref_off), f"offsets (flags {flags}, encoder {eimpl})"
+                    assert np.array_equal(w, ref_w), f"stream (flags {flags}, encoder {eimpl})"
+            ctx.set_option("encode_impl", 1)
+            enc = dr.EncodedBatch(dev(ctx, ref_w.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), ref_w.size)
+            lossless = taps is None or abs(taps[0]) == 1
+            expect = x
+            if not lossless:
+                expect = np.concatenate([O.decode_chunk(ww, opts) for ww in words])
+            for flags, impl in ((0, 8), (256, 8), (512, 8), (0, 7), (0, 1), (0, 0), (0, 14)):
+                ctx.set_option("debug_flags", flags)
+                ctx.set_option("decode_impl", impl)
+                y = plan.decode(enc).cpu().numpy()
+                assert np.array_equal(y, expect), f"decode (flags {flags}, impl {impl})"
+            ctx.set_option("debug_flags", 0)
+            ctx.set_option("decode_impl", 8)
+        except Exception as e:  # noqa: BLE001
+            print("FAIL", label, "->", repr(e), flush=True)
+            return 1
+        if it % 20 == 19:
+            print(f"{it + 1} cases ok ({time.time() - t0:.0f} s)", flush=True)
+    print(f"all {cases} cases ok (seed {seed}, {time.time() - t0:.0f} s)")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

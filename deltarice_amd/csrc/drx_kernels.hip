@@ -851,7 +851,8 @@ __device__ __forceinline__ void for_segment_tiles(const int16_t *__restrict__ xw
     const int16_t *x = xw + q.start;
     const bool vec_ok = ((uintptr_t)x & 15u) == 0;
     // dword whose high half is the sample before the segment (x[-1] := 0 at the start of the waveform, :53-54)
-    uint32_t carry = q.start ? ((uint32_t)(uint16_t)xw[q.start - 1u] << 16) : 0u;
+    // (a unit past the end of a shorter last waveform has count == 0: nothing of it may be touched)
+    uint32_t carry = (q.start && q.count) ? ((uint32_t)(uint16_t)xw[q.start - 1u] << 16) : 0u;
     const u16x2 tp[4] = {splat(1u), splat(0xffffu), splat(0u), splat(0u)};
     for (uint32_t t0 = 0; t0 < q.count; t0 += kTile) {
         uint32_t w[4];

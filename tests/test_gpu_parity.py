@@ -461,3 +461,17 @@ def test_randomised_shapes_vs_oracle():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "120", "11"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_segment_encoder_units_past_a_short_last_waveform(ctx, O):
+    """Regression (found by tools/fuzz_parity.py): a chunk of 400 000 samples at WaveformLength 300 000 has a last
+    waveform of 100 000 samples; the segment encoder's units past its end once read the sample in front of a
+    segment that does not exist -- out of bounds."""
+    x = np.zeros(400_000, np.int16)
+    x[::7] = 5
+    for opts in ((1024, 300_000), (8, 300_000)):
+        ref_w, ref_off = O.encode_batch(x, x.size, opts)
+        plan = ctx.plan_uniform(1, x.size, opts)
+        w, off = plan.encode(dev(ctx, x)).to_numpy()
+        assert np.array_equal(off, ref_off) and np.array_equal(w, ref_w)
+        assert np.array_equal(plan.decode(plan.encode(dev(ctx, x))).cpu().numpy(), x)

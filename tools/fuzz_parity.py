@@ -42,6 +42,17 @@ def main():
     rng = np.random.default_rng(seed)
     ctx = dr.Context(0)
     t0 = time.time()
+    lo, hi = 0, cases
+    if os.environ.get("DRX_FUZZ_ONLY"):
+        lo, hi = (int(v) for v in os.environ["DRX_FUZZ_ONLY"].split(":"))
+    logf = open(os.environ["DRX_FUZZ_LOG"], "a") if os.environ.get("DRX_FUZZ_LOG") else None
+
+    def log(msg):
+        if logf:
+            logf.write(msg + "\n")
+            logf.flush()
+            os.fsync(logf.fileno())
+
     for it in range(cases):
         k = int(rng.integers(1, 16)) if rng.random() < 0.9 else 0
         kind = str(rng.choice(["gauss", "uniform", "zeros", "ramp", "pulses"]))
@@ -66,6 +77,9 @@ def main():
         if k == 0:
             x = (x // 4).astype(np.int16)
         label = f"case {it}: k={k} {kind} chunks={n_chunks} L={Ls} N={Ns} taps={taps}"
+        if it < lo or it >= hi:
+            continue
+        log(label)
         try:
             # oracle stream, chunk by chunk
             words, offs = [], [0]
@@ -88,6 +102,7 @@ def main():
                 ctx.set_option("debug_flags", flags)
                 for eimpl in (1, 0):
                     ctx.set_option("encode_impl", eimpl)
+                    log(f"  encode flags {flags} impl {eimpl}")
                     w, off = plan.encode(xd).to_numpy()
                     assert np.array_equal(off, ref_off), f"offsets (flags {flags}, encoder {eimpl})"
                     assert np.array_equal(w, ref_w), f"stream (flags {flags}, encoder {eimpl})"
@@ -100,6 +115,7 @@ def main():
             for flags, impl in ((0, 8), (256, 8), (512, 8), (0, 7), (0, 1), (0, 0), (0, 14)):
                 ctx.set_option("debug_flags", flags)
                 ctx.set_option("decode_impl", impl)
+                log(f"  decode flags {flags} impl {impl}")
                 y = plan.decode(enc).cpu().numpy()
                 assert np.array_equal(y, expect), f"decode (flags {flags}, impl {impl})"
             ctx.set_option("debug_flags", 0)

@@ -120,6 +120,25 @@ def main():
                 assert np.array_equal(y, expect), f"decode (flags {flags}, impl {impl})"
             ctx.set_option("debug_flags", 0)
             ctx.set_option("decode_impl", 8)
+            if os.environ.get("DRX_FUZZ_CORRUPT"):
+                # payload bits flipped (headers intact): any result or DRX_ERR_CORRUPT is fine, a fault is not
+                bad = ref_w.copy()
+                hdr = set(int(o) for o in ref_off[:-1])
+                for _ in range(4):
+                    j = int(rng.integers(0, bad.size))
+                    if j not in hdr:
+                        bad[j] ^= np.uint32(1 << int(rng.integers(0, 32)))
+                encb = dr.EncodedBatch(dev(ctx, bad.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), bad.size)
+                for flags, impl in ((0, 8), (256, 8), (512, 8), (0, 1), (0, 0)):
+                    ctx.set_option("debug_flags", flags)
+                    ctx.set_option("decode_impl", impl)
+                    log(f"  corrupt decode flags {flags} impl {impl}")
+                    try:
+                        plan.decode(encb)
+                    except dr.DeltaRiceError:
+                        pass
+                ctx.set_option("debug_flags", 0)
+                ctx.set_option("decode_impl", 8)
         except Exception as e:  # noqa: BLE001
             print("FAIL", label, "->", repr(e), flush=True)
             return 1

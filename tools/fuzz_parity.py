@@ -120,6 +120,13 @@ def main():
                 assert np.array_equal(y, expect), f"decode (flags {flags}, impl {impl})"
             ctx.set_option("debug_flags", 0)
             ctx.set_option("decode_impl", 8)
+            # the one-chunk host path (what the H5Z callback runs) on the first chunk
+            opts0 = (1 << k, Ls[0]) + ((len(taps),) + tuple(t & 0xFFFFFFFF for t in taps) if taps else ())
+            log("  host path")
+            eb = ctx.filter_chunk(x[:Ns[0]], opts0, reverse=False)
+            assert eb == words[0].tobytes(), "host path encode"
+            db = np.frombuffer(ctx.filter_chunk(eb, opts0, reverse=True), np.int16)
+            assert np.array_equal(db, expect[:Ns[0]]), "host path decode"
             if os.environ.get("DRX_FUZZ_CORRUPT"):
                 # payload bits flipped (headers intact): any result or DRX_ERR_CORRUPT is fine, a fault is not
                 bad = ref_w.copy()

@@ -1357,7 +1357,13 @@ __global__ __launch_bounds__(kLongThreads) void k_decode_long(Geom G, const uint
                                                               uint64_t *__restrict__ state, uint32_t *__restrict__ ticket,
                                                               uint32_t *__restrict__ fail) {
     constexpr uint32_t NT = kLongThreads;
-    __shared__ uint32_t col[(kLongSeg + kLongOv) * NT];  // [word of the segment][thread]: a lane's bank is its lane number
+    // [kLongRows - 2 - word of the segment][thread] (a lane's bank is its lane number whatever row it reads), rows
+    // in REVERSE word order plus one unused row on top: with the bit position kept negated, Q = -pos, the row
+    // pair (Q >> 5, Q >> 5 + 1) is (word w + 1, word w) inside a word and (word w, word w - 1) on a word
+    // boundary, and v_alignbit_b32(hi, lo, Q) is the 32-bit window in both cases (as in k_decode_lanes)
+    // (+ 2 rows below: a lane that has left its segment keeps reading at its last position, up to 49 bits past it)
+    constexpr uint32_t kLongRows = kLongSeg + kLongOv + 3;
+    __shared__ uint32_t col[kLongRows * NT];
     __shared__ uint32_t s_end[NT];
     __shared__ uint32_t s_tot[2][kLongWaves];
     __shared__ uint64_t s_bcast[2];
@@ -1389,54 +1395,59 @@ __global__ __launch_bounds__(kLongThreads) void k_decode_long(Geom G, const uint
     uint32_t carry_in = (MULTI && blk) ? tail_end[unit - 1u] : 0u;  // bit of thread 0's segment at which the next code starts
     uint32_t done = 0;      // samples written
     uint32_t acc_base = 0;  // running sum before the block (mod 2^16)
-    const uint32_t *mycol = col + tid;
 
     // parses this thread's segment from bit `start`; a code is taken when it STARTS inside the segment and inside
     // the stream.  emit: add to the running sum `acc` and store sample number idx, idx + 1, ...
     auto parse = [&](bool enable, uint32_t start, uint32_t avail_bits, auto emit_tag, uint32_t idx, uint32_t acc,
                      uint32_t &end, uint32_t &cnt, uint32_t &sum) __attribute__((always_inline)) {
         constexpr bool EMIT = decltype(emit_tag)::value;
-        uint32_t pos = start, c = 0, sacc = EMIT ? acc : 0u;
+        uint32_t c = 0, sacc = EMIT ? acc : 0u;
+        uint32_t Q = 0u - start;  // minus the bit position
         const uint32_t lim = avail_bits < kLongSegBits ? avail_bits : kLongSegBits;
+        const int32_t nlim = enable ? -(int32_t)lim : 1;  // a code is taken while -Q < lim, i.e. Q > -lim
         // EMIT: two samples per store where they share an aligned dword (2-byte stores run into the L2's request
         // rate: 350 M of them in 2 ms); held: the sample waiting for its partner
         const uint32_t par0 = (uint32_t)(((uintptr_t)y >> 1) & 1u);  // parity of sample 0's address in int16 units
         uint32_t held = 0, held_i = 0;
         bool holding = false;
-        while (__any(enable && pos < lim)) {
+        // LDS byte address of this thread's row of word 0
+        const uint32_t row0 = lds_addr(col) + ((kLongRows - 2u) * NT + tid) * 4u;
+        while (__any((int32_t)Q > nlim)) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {  // one vote per four codes
-                const bool act = enable && pos < lim;
-                const uint32_t w = act ? pos >> 5 : 0u;
-                const uint64_t two = ((uint64_t)mycol[w * NT] << 32) | mycol[(w + 1u) * NT];
-                const uint32_t win = (uint32_t)((two << (pos & 31u)) >> 32);
-                const uint32_t q = win ? (uint32_t)__builtin_clz(win) : 32u;
+                const bool act = (int32_t)Q > nlim;
+                typedef const uint32_t __attribute__((address_space(3))) lds_cu32;
+                const lds_cu32 *wp = (const lds_cu32 *)(uintptr_t)(row0 + (uint32_t)(((int32_t)Q >> 5) * (int32_t)(NT * 4u)));
+                const uint32_t lo = wp[0], hi = wp[NT];
+                const uint32_t win = __builtin_amdgcn_alignbit(hi, lo, Q);
+                const uint32_t q = (uint32_t)__builtin_clz(win);  // all-zero window (padding): the hardware's -1 is as good as any
                 const uint32_t kk = (win < (1u << 24)) ? 16u : k;
-                const uint32_t used = q + kk + 1u;
-                const uint32_t rem = __builtin_amdgcn_ubfe(win, 32u - used, kk);
-                const uint32_t z = (q << kk) + rem;
+                const uint32_t nu = ~(q + kk);  // minus the code length
+                const uint32_t z = (q << kk) + __builtin_amdgcn_ubfe(win, nu, kk);
                 const uint32_t d = (z >> 1) ^ (0u - (z & 1u));
-                if (act) {
-                    sacc += d;
-                    if (EMIT && idx + c < len) {
+                const uint32_t s2 = sacc + d;
+                if (EMIT) {
+                    if (act && idx + c < len) {
                         const uint32_t i = idx + c;
                         if (((i + par0) & 1u) == 0u) {  // low half of an aligned dword: wait for the next sample
-                            held = sacc & 0xffffu;
+                            held = s2 & 0xffffu;
                             held_i = i;
                             holding = true;
                         } else if (holding) {
-                            *reinterpret_cast<uint32_t *>(y + i - 1u) = held | (sacc << 16);
+                            *reinterpret_cast<uint32_t *>(y + i - 1u) = held | (s2 << 16);
                             holding = false;
                         } else {
-                            y[i] = (int16_t)(uint16_t)sacc;  // the lane's first sample sits in a high half
+                            y[i] = (int16_t)(uint16_t)s2;  // the lane's first sample sits in a high half
                         }
                     }
-                    ++c;
-                    pos += used;
                 }
+                sacc = act ? s2 : sacc;
+                Q = act ? Q + nu : Q;
+                c += act ? 1u : 0u;
             }
         }
         if (EMIT && holding) y[held_i] = (int16_t)(uint16_t)held;  // the lane's last sample had no partner
+        const uint32_t pos = 0u - Q;
         end = pos;
         cnt = c;
         sum = sacc;
@@ -1449,12 +1460,12 @@ __global__ __launch_bounds__(kLongThreads) void k_decode_long(Geom G, const uint
             const uint32_t j = tid + NT * (uint32_t)rr;
             const uint32_t wvl = (blk_word + j < n) ? src[blk_word + j] : 0u;
             const uint32_t sgm = j / kLongSeg, i = j % kLongSeg;
-            col[i * NT + sgm] = wvl;
-            if (i < (uint32_t)kLongOv && sgm >= 1u) col[((uint32_t)kLongSeg + i) * NT + sgm - 1u] = wvl;
+            col[(kLongRows - 2u - i) * NT + sgm] = wvl;
+            if (i < (uint32_t)kLongOv && sgm >= 1u) col[(kLongRows - 2u - ((uint32_t)kLongSeg + i)) * NT + sgm - 1u] = wvl;
         }
         if (tid < (uint32_t)kLongOv) {
             const uint32_t wi = blk_word + NT * kLongSeg + tid;
-            col[((uint32_t)kLongSeg + tid) * NT + NT - 1u] = (wi < n) ? src[wi] : 0u;
+            col[(kLongRows - 2u - ((uint32_t)kLongSeg + tid)) * NT + NT - 1u] = (wi < n) ? src[wi] : 0u;
         }
         __syncthreads();
         const uint32_t seg_word = blk_word + tid * kLongSeg;

@@ -60,6 +60,7 @@ struct drx_plan {
     uint32_t *d_seg_bits = nullptr;    // few long waveforms: bits and bit position of every 8192-sample segment,
     uint64_t *d_seg_pos = nullptr;     // allocated by the first encode that needs them
     uint64_t *d_long = nullptr;        // a handful of long waveforms: scratch of the workgroup-per-block decoder
+    uint64_t *d_seg_unit_base = nullptr;  // ragged plans the segment encoder takes
     uint32_t *d_walk_lists = nullptr;  // ragged plans: chunk indices, short-waveform chunks first
     uint32_t n_short = 0, n_long = 0;
     DevStatus *d_status = nullptr;
@@ -216,6 +217,7 @@ static void plan_free(drx_plan *p) {
     if (p->d_seg_bits) (void)hipFree(p->d_seg_bits);
     if (p->d_seg_pos) (void)hipFree(p->d_seg_pos);
     if (p->d_long) (void)hipFree(p->d_long);
+    if (p->d_seg_unit_base) (void)hipFree(p->d_seg_unit_base);
     if (p->d_status) (void)hipFree(p->d_status);
     if (p->h_status) (void)hipHostFree(p->h_status);
     for (hipEvent_t e : p->ev) if (e) (void)hipEventDestroy(e);
@@ -291,6 +293,20 @@ drx_status drx_plan_create(drx_ctx *ctx, uint64_t n_chunks, const uint32_t *chun
         p->G.n_short = p->n_short;
         p->G.n_long = p->n_long;
         p->G.max_groups = max_groups;
+        // the segment encoder for ragged batches with short (<= 2048) or long (>= 16384) waveforms somewhere: unit
+        // (waveform x 8192-sample segment slot) numbering per chunk
+        bool seg = false;
+        std::vector<uint64_t> ub(n_chunks + 1, 0);
+        for (uint64_t c = 0; c < n_chunks; ++c) {
+            seg = seg || desc[c].wave_len <= kWalkShortLenHost || desc[c].wave_len >= 16384u;
+            ub[c + 1] = ub[c] + (uint64_t)desc[c].n_waves * ((desc[c].wave_len + 8191u) / 8192u);
+        }
+        if (seg) {
+            if (e == hipSuccess) e = hipMalloc((void **)&p->d_seg_unit_base, ub.size() * sizeof(uint64_t));
+            if (e == hipSuccess) e = hipMemcpy(p->d_seg_unit_base, ub.data(), ub.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
+            p->G.seg_unit_base = p->d_seg_unit_base;
+            p->G.seg_units = ub[n_chunks];
+        }
         if (e != hipSuccess) st = fail(ctx, DRX_ERR_DEVICE, "chunk table upload failed: %s", hipGetErrorString(e));
     }
     if (st != DRX_OK) { plan_free(p); return st; }
@@ -384,7 +400,7 @@ drx_status drx_encode(drx_plan *p, const int16_t *d_in, uint32_t *d_out, uint64_
     p->G.dbg = ctx->debug_flags;
     if (ctx->encode_impl == 1 && long_batch(p->G) && !(ctx->debug_flags & 256u)) {
         if (!p->d_seg_bits) {
-            const uint64_t units = p->G.total_waves * long_batch_segments(p->G);
+            const uint64_t units = long_batch_units(p->G);
             DRX_HIP(ctx, hipMalloc((void **)&p->d_seg_bits, units * sizeof(uint32_t)));
             DRX_HIP(ctx, hipMalloc((void **)&p->d_seg_pos, units * sizeof(uint64_t)));
         }

@@ -49,6 +49,10 @@ struct Geom {
     // (walk_short[n_short], then walk_long[n_long]), and the largest ceil(n_waves / 64) of any chunk
     const uint32_t *walk_short, *walk_long;
     uint32_t n_short, n_long, max_groups;
+    // ragged batches that the segment encoder takes (some chunk has short or long waveforms): first unit (waveform x
+    // segment slot) of every chunk, n_chunks + 1 entries, and their total
+    const uint64_t *seg_unit_base;
+    uint64_t seg_units;
 };
 
 struct DevStatus {
@@ -73,7 +77,7 @@ hipError_t launch_encode_fused(const Geom &G, const int16_t *d_in, uint32_t *d_o
 
 // few long waveforms (WaveformLength = -1): a wavefront per 8192-sample segment, see drx_kernels.hip
 bool long_batch(const Geom &G);
-uint32_t long_batch_segments(const Geom &G);
+uint64_t long_batch_units(const Geom &G);
 hipError_t launch_encode_long(const Geom &G, const int16_t *d_in, uint32_t *d_out, uint64_t out_cap,
                               uint64_t *d_chunk_word_off, uint32_t *d_wave_words, uint32_t *d_wave_rel,
                               uint64_t *d_chunk_words, uint32_t *d_seg_bits, uint64_t *d_seg_pos, DevStatus *d_status,

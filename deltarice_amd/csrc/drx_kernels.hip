@@ -836,9 +836,28 @@ struct SegRef {
 
 __device__ __forceinline__ SegRef locate_seg(const Geom &G, uint64_t u, uint32_t segs_per_wave) {
     SegRef q;
-    q.g = u / segs_per_wave;
-    q.s = (uint32_t)(u - q.g * segs_per_wave);
-    q.r = locate(G, q.g);
+    if (G.uniform) {
+        q.g = u / segs_per_wave;
+        q.s = (uint32_t)(u - q.g * segs_per_wave);
+        q.r = locate(G, q.g);
+    } else {
+        uint64_t lo = 0, hi = G.n_chunks;  // invariant: seg_unit_base[lo] <= u < seg_unit_base[hi]
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (G.seg_unit_base[mid] <= u) lo = mid; else hi = mid;
+        }
+        const ChunkDesc d = G.chunks[lo];
+        const uint32_t S = (d.wave_len + kSegSamples - 1u) / kSegSamples;
+        const uint64_t local = u - G.seg_unit_base[lo];
+        const uint32_t idx = (uint32_t)(local / S);
+        q.s = (uint32_t)(local - (uint64_t)idx * S);
+        q.g = d.wave_base + idx;
+        q.r.chunk = lo;
+        q.r.idx = idx;
+        q.r.n_samples = d.n_samples;
+        q.r.sample_off = d.sample_off + (uint64_t)idx * d.wave_len;
+        q.r.len = (idx + 1 == d.n_waves) ? (d.n_samples - idx * d.wave_len) : d.wave_len;
+    }
     q.start = q.s * kSegSamples;
     q.count = q.start < q.r.len ? ((q.r.len - q.start) < kSegSamples ? (q.r.len - q.start) : kSegSamples) : 0u;
     q.last = q.start + q.count == q.r.len;
@@ -885,17 +904,24 @@ __global__ __launch_bounds__(256) void k_seg_sizes(Geom G, const int16_t *__rest
 
 // one wavefront per waveform: exclusive prefix of its segments' bits (a waveform has < 2^31 * 25 / 2^32 ... bits
 // fit 64, positions inside one waveform are kept in 64 bits), n_i
-__global__ __launch_bounds__(64) void k_seg_scan(uint64_t total_waves, uint32_t segs_per_wave, const uint32_t *__restrict__ seg_bits,
+__global__ __launch_bounds__(64) void k_seg_scan(Geom G, uint32_t segs_uniform, const uint32_t *__restrict__ seg_bits,
                                                  uint64_t *__restrict__ seg_pos, uint32_t *__restrict__ wave_words) {
     const int lane = lane_id();
     const uint64_t g = blockIdx.x;
-    if (g >= total_waves) return;
+    if (g >= G.total_waves) return;
+    uint32_t segs_per_wave = segs_uniform;
+    uint64_t first = g * segs_uniform;  // the waveform's first unit
+    if (!G.uniform) {
+        const WaveRef r = locate(G, g);
+        segs_per_wave = (G.chunks[r.chunk].wave_len + kSegSamples - 1u) / kSegSamples;
+        first = G.seg_unit_base[r.chunk] + (uint64_t)r.idx * segs_per_wave;
+    }
     uint64_t run = 0;
     for (uint32_t s0 = 0; s0 < segs_per_wave; s0 += 64) {
         const uint32_t sidx = s0 + (uint32_t)lane;
-        const uint32_t v = sidx < segs_per_wave ? seg_bits[g * segs_per_wave + sidx] : 0u;
+        const uint32_t v = sidx < segs_per_wave ? seg_bits[first + sidx] : 0u;
         const uint32_t inc = wave_incl_scan_dpp(v);  // 64 * 204 800 bits fit 32
-        if (sidx < segs_per_wave) seg_pos[g * segs_per_wave + sidx] = run + inc - v;
+        if (sidx < segs_per_wave) seg_pos[first + sidx] = run + inc - v;
         run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
     }
     if (lane == 0) wave_words[g] = (uint32_t)((run + 31u) >> 5);
@@ -2119,9 +2145,12 @@ uint64_t long_decode_scratch_bytes(const Geom &G) {
 // (200 chunks of 14 M samples: L = 512 0.57 -> 0.95 TB/s, 1024 0.97 -> 1.33, 2048 1.51 -> 1.68; 7000 is better off
 // with the single pass)
 bool long_batch(const Geom &G) {
-    return G.uniform && G.n_taps == 0 && (long_waveform_batch(G.total_waves, G.u_wave_len) || G.u_wave_len <= kWalkShortLen);
+    if (G.n_taps) return false;
+    if (!G.uniform) return G.seg_unit_base != nullptr;  // decided when the plan was made (some chunk is short or long)
+    return long_waveform_batch(G.total_waves, G.u_wave_len) || G.u_wave_len <= kWalkShortLen;
 }
-uint32_t long_batch_segments(const Geom &G) { return (G.u_wave_len + kSegSamples - 1u) / kSegSamples; }
+static uint32_t uniform_segments(const Geom &G) { return (G.u_wave_len + kSegSamples - 1u) / kSegSamples; }
+uint64_t long_batch_units(const Geom &G) { return G.uniform ? G.total_waves * uniform_segments(G) : G.seg_units; }
 
 // Encoder for few long waveforms.  d_seg_bits: uint32[total_waves * segments], d_seg_pos: uint64[same].
 hipError_t launch_encode_long(const Geom &G, const int16_t *d_in, uint32_t *d_out, uint64_t out_cap,
@@ -2129,12 +2158,12 @@ hipError_t launch_encode_long(const Geom &G, const int16_t *d_in, uint32_t *d_ou
                               uint64_t *d_chunk_words, uint32_t *d_seg_bits, uint64_t *d_seg_pos, DevStatus *d_status,
                               hipEvent_t *ev, hipStream_t s) {
     if (G.total_waves == 0) return hipSuccess;
-    const uint32_t S = long_batch_segments(G);
-    const uint64_t units = G.total_waves * S;
+    const uint32_t S = G.uniform ? uniform_segments(G) : 0u;
+    const uint64_t units = long_batch_units(G);
     mark(ev, 0, s);
     k_seg_sizes<<<blocks_for(units, 4), 256, 0, s>>>(G, d_in, S, units, d_seg_bits);
     mark(ev, 1, s);
-    k_seg_scan<<<(unsigned)G.total_waves, 64, 0, s>>>(G.total_waves, S, d_seg_bits, d_seg_pos, d_wave_words);
+    k_seg_scan<<<(unsigned)G.total_waves, 64, 0, s>>>(G, S, d_seg_bits, d_seg_pos, d_wave_words);
     k_chunk_scan<<<(unsigned)G.n_chunks, 256, 0, s>>>(G, d_wave_words, d_wave_rel, d_chunk_words);
     k_chunk_offsets<<<1, 1024, 0, s>>>(G.n_chunks, d_chunk_words, d_chunk_word_off, out_cap, d_status);
     k_seg_zero<<<blocks_for(units, 256), 256, 0, s>>>(G, S, units, d_seg_pos, d_wave_rel, d_chunk_word_off, d_out, out_cap);

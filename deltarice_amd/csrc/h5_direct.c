@@ -61,7 +61,8 @@ drx_status drx_h5_read(drx_ctx *ctx, const char *file, const char *name, int16_t
     hid_t f = -1, d = -1, sp = -1, pl = -1;
     void *h_words = NULL, *d_words = NULL;
     uint64_t *h_off = NULL, *d_off = NULL;
-    drx_plan *plan = NULL;
+    drx_plan *plan = NULL, *plan_edge = NULL;
+    void *d_edge = NULL;
     double t0 = now();
 
     if ((f = H5Fopen(file, H5F_ACC_RDONLY, H5P_DEFAULT)) < 0) goto out;
@@ -70,25 +71,28 @@ drx_status drx_h5_read(drx_ctx *ctx, const char *file, const char *name, int16_t
     pl = H5Dget_create_plist(d);
     hsize_t dims[2], chunk[2];
     if (H5Sget_simple_extent_ndims(sp) != 2 || H5Sget_simple_extent_dims(sp, dims, NULL) < 0) goto out;
-    if (H5Pget_chunk(pl, 2, chunk) != 2 || chunk[1] != dims[1] || dims[0] % chunk[0]) { rc = DRX_ERR_UNSUPPORTED; goto out; }
+    if (H5Pget_chunk(pl, 2, chunk) != 2 || chunk[1] != dims[1]) { rc = DRX_ERR_UNSUPPORTED; goto out; }
     {
         hid_t ty = H5Dget_type(d);
         const int ok = H5Tget_class(ty) == H5T_INTEGER && H5Tget_size(ty) == 2;
         H5Tclose(ty);
         if (!ok) { rc = DRX_ERR_UNSUPPORTED; goto out; }
     }
-    unsigned cd[8], flags = 0, fcfg = 0;
-    size_t ncd = 8;
+    unsigned cd[3 + DRX_MAX_TAPS], flags = 0, fcfg = 0;
+    size_t ncd = 3 + DRX_MAX_TAPS;
     char fname[8];
     if (H5Pget_nfilters(pl) != 1 ||
-        H5Pget_filter_by_id2(pl, FILTER_ID, &flags, &ncd, cd, sizeof fname, fname, &fcfg) < 0 || ncd > 2) {
-        rc = DRX_ERR_UNSUPPORTED;  /* other filters in the pipeline, or a general prediction filter */
+        H5Pget_filter_by_id2(pl, FILTER_ID, &flags, &ncd, cd, sizeof fname, fname, &fcfg) < 0) {
+        rc = DRX_ERR_UNSUPPORTED;  /* other filters in the pipeline */
         goto out;
     }
-    unsigned k = 3, L = 0;
-    if (ncd >= 1 && log2_m(cd[0], &k)) goto out;
-    if (ncd >= 2) L = (cd[1] == 0xffffffffu) ? 0u : cd[1];
-    s.rows = dims[0]; s.cols = dims[1]; s.chunk_rows = chunk[0]; s.n_chunks = dims[0] / chunk[0];
+    drx_opts o;
+    if (drx_parse_cd_values(ncd, cd, &o) != DRX_OK) goto out;
+    const unsigned k = o.rice_k, L = o.wave_len < 0 ? 0u : (unsigned)o.wave_len;
+    /* HDF5 stores the last chunk full size when the rows do not divide: it is decoded into scratch and the
+     * rows that exist are copied out */
+    const uint64_t n_full = dims[0] / chunk[0], edge_rows = dims[0] % chunk[0];
+    s.rows = dims[0]; s.cols = dims[1]; s.chunk_rows = chunk[0]; s.n_chunks = n_full + (edge_rows ? 1 : 0);
     s.raw_bytes = dims[0] * dims[1] * 2;
     if (dims[0] * dims[1] > out_cap_samples) { rc = DRX_ERR_CAPACITY; goto out; }
     if (chunk[0] * chunk[1] > 0x7fffffffull) goto out;
@@ -122,12 +126,28 @@ drx_status drx_h5_read(drx_ctx *ctx, const char *file, const char *name, int16_t
     s.t_pcie = now() - t0;
 
     t0 = now();
-    if ((rc = drx_plan_create_uniform(ctx, s.n_chunks, (uint32_t)(chunk[0] * chunk[1]), L, k, &plan)) != DRX_OK) goto out;
-    if ((rc = drx_decode(plan, (const uint32_t *)d_words, words, d_off, d_out)) != DRX_OK) goto out;
-    rc = drx_plan_finish(plan, NULL);
+    const uint32_t chunk_samples = (uint32_t)(chunk[0] * chunk[1]);
+    if (n_full) {
+        if ((rc = drx_plan_create_uniform(ctx, n_full, chunk_samples, L, k, &plan)) != DRX_OK) goto out;
+        if ((rc = drx_plan_set_filter(plan, o.n_taps, o.taps)) != DRX_OK) goto out;
+        if ((rc = drx_decode(plan, (const uint32_t *)d_words, words, d_off, d_out)) != DRX_OK) goto out;
+        if ((rc = drx_plan_finish(plan, NULL)) != DRX_OK) goto out;
+    }
+    if (edge_rows) {
+        if (hipMalloc(&d_edge, (size_t)chunk_samples * 2) != hipSuccess) { rc = DRX_ERR_NOMEM; goto out; }
+        if ((rc = drx_plan_create_uniform(ctx, 1, chunk_samples, L, k, &plan_edge)) != DRX_OK) goto out;
+        if ((rc = drx_plan_set_filter(plan_edge, o.n_taps, o.taps)) != DRX_OK) goto out;
+        if ((rc = drx_decode(plan_edge, (const uint32_t *)d_words, words, d_off + n_full, (int16_t *)d_edge)) != DRX_OK) goto out;
+        if ((rc = drx_plan_finish(plan_edge, NULL)) != DRX_OK) goto out;
+        if (hipMemcpyAsync(d_out + n_full * chunk_samples, d_edge, (size_t)(edge_rows * dims[1]) * 2, hipMemcpyDeviceToDevice, stream) != hipSuccess ||
+            hipStreamSynchronize(stream) != hipSuccess) { rc = DRX_ERR_DEVICE; goto out; }
+    }
+    rc = DRX_OK;
     s.t_gpu = now() - t0;
 out:
     if (plan) drx_plan_destroy(plan);
+    if (plan_edge) drx_plan_destroy(plan_edge);
+    if (d_edge) (void)hipFree(d_edge);
     if (d_words) (void)hipFree(d_words);
     if (d_off) (void)hipFree(d_off);
     if (h_words) (void)hipHostFree(h_words);
@@ -143,39 +163,56 @@ out:
 drx_status drx_h5_write(drx_ctx *ctx, const char *file, const char *name, const int16_t *d_in,
                         uint64_t rows, uint64_t cols, uint64_t chunk_rows, unsigned rice_m,
                         unsigned wave_len, drx_h5_stats *st) {
-    if (!ctx || !file || !name || !d_in || !rows || !cols || !chunk_rows || rows % chunk_rows) return DRX_ERR_ARG;
+    if (!ctx || !file || !name || !d_in || !rows || !cols || !chunk_rows || chunk_rows > rows) return DRX_ERR_ARG;  /* HDF5: chunk <= dataset */
     drx_h5_stats s;
     memset(&s, 0, sizeof s);
     unsigned k;
     if (log2_m(rice_m, &k) || chunk_rows * cols > 0x7fffffffull) return DRX_ERR_ARG;
-    s.rows = rows; s.cols = cols; s.chunk_rows = chunk_rows; s.n_chunks = rows / chunk_rows;
+    /* rows that do not divide: HDF5 stores the last chunk full size, padded with the fill value (0) */
+    const uint64_t n_full = rows / chunk_rows, edge_rows = rows % chunk_rows;
+    const uint32_t chunk_samples = (uint32_t)(chunk_rows * cols);
+    s.rows = rows; s.cols = cols; s.chunk_rows = chunk_rows; s.n_chunks = n_full + (edge_rows ? 1 : 0);
     s.raw_bytes = rows * cols * 2;
     drx_status rc = DRX_ERR_DEVICE;
-    drx_plan *plan = NULL;
-    void *d_words = NULL, *h_words = NULL;
+    drx_plan *plan = NULL, *plan_edge = NULL;
+    void *d_words = NULL, *h_words = NULL, *d_edge = NULL, *d_words_e = NULL;
     uint64_t *d_off = NULL, *h_off = NULL;
     hid_t f = -1, d = -1, sp = -1, pl = -1;
     hipStream_t stream = (hipStream_t)drx_ctx_stream(ctx);
 
     double t0 = now();
-    if ((rc = drx_plan_create_uniform(ctx, s.n_chunks, (uint32_t)(chunk_rows * cols), wave_len, k, &plan)) != DRX_OK) goto out;
-    const uint64_t cap = drx_plan_max_encoded_words(plan);
-    uint64_t words = 0;
-    rc = DRX_ERR_NOMEM;
-    if (hipMalloc(&d_words, cap * 4) != hipSuccess || hipMalloc((void **)&d_off, (s.n_chunks + 1) * 8) != hipSuccess) goto out;
-    if ((rc = drx_encode(plan, d_in, (uint32_t *)d_words, cap, d_off)) != DRX_OK) goto out;
-    if ((rc = drx_plan_finish(plan, &words)) != DRX_OK) goto out;
+    uint64_t words = 0, words_e = 0, cap = 0, cap_e = 0;
+    if (hipMalloc((void **)&d_off, (s.n_chunks + 3) * 8) != hipSuccess) { rc = DRX_ERR_NOMEM; goto out; }
+    if (n_full) {
+        if ((rc = drx_plan_create_uniform(ctx, n_full, chunk_samples, wave_len, k, &plan)) != DRX_OK) goto out;
+        cap = drx_plan_max_encoded_words(plan);
+        if (hipMalloc(&d_words, cap * 4) != hipSuccess) { rc = DRX_ERR_NOMEM; goto out; }
+        if ((rc = drx_encode(plan, d_in, (uint32_t *)d_words, cap, d_off)) != DRX_OK) goto out;
+        if ((rc = drx_plan_finish(plan, &words)) != DRX_OK) goto out;
+    }
+    if (edge_rows) {
+        if ((rc = drx_plan_create_uniform(ctx, 1, chunk_samples, wave_len, k, &plan_edge)) != DRX_OK) goto out;
+        cap_e = drx_plan_max_encoded_words(plan_edge);
+        if (hipMalloc(&d_edge, (size_t)chunk_samples * 2) != hipSuccess || hipMalloc(&d_words_e, cap_e * 4) != hipSuccess) { rc = DRX_ERR_NOMEM; goto out; }
+        if (hipMemsetAsync(d_edge, 0, (size_t)chunk_samples * 2, stream) != hipSuccess ||
+            hipMemcpyAsync(d_edge, d_in + n_full * chunk_samples, (size_t)(edge_rows * cols) * 2, hipMemcpyDeviceToDevice, stream) != hipSuccess) { rc = DRX_ERR_DEVICE; goto out; }
+        if ((rc = drx_encode(plan_edge, (const int16_t *)d_edge, (uint32_t *)d_words_e, cap_e, d_off + n_full + 1)) != DRX_OK) goto out;
+        if ((rc = drx_plan_finish(plan_edge, &words_e)) != DRX_OK) goto out;
+    }
     s.t_gpu = now() - t0;
-    s.stored_bytes = words * 4;
+    s.stored_bytes = (words + words_e) * 4;
 
     t0 = now();
     rc = DRX_ERR_NOMEM;
-    h_off = (uint64_t *)malloc((s.n_chunks + 1) * 8);
-    if (!h_off || hipHostMalloc(&h_words, words * 4, hipHostMallocDefault) != hipSuccess) goto out;
+    h_off = (uint64_t *)malloc((s.n_chunks + 3) * 8);
+    if (!h_off || hipHostMalloc(&h_words, (words + words_e + 1) * 4, hipHostMallocDefault) != hipSuccess) goto out;
     rc = DRX_ERR_DEVICE;
-    if (hipMemcpyAsync(h_words, d_words, words * 4, hipMemcpyDeviceToHost, stream) != hipSuccess ||
-        hipMemcpyAsync(h_off, d_off, (s.n_chunks + 1) * 8, hipMemcpyDeviceToHost, stream) != hipSuccess ||
-        hipStreamSynchronize(stream) != hipSuccess) goto out;
+    h_off[0] = 0;
+    if (n_full && (hipMemcpyAsync(h_words, d_words, words * 4, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+                   hipMemcpyAsync(h_off, d_off, (n_full + 1) * 8, hipMemcpyDeviceToHost, stream) != hipSuccess)) goto out;
+    if (edge_rows && hipMemcpyAsync((uint32_t *)h_words + words, d_words_e, words_e * 4, hipMemcpyDeviceToHost, stream) != hipSuccess) goto out;
+    if (hipStreamSynchronize(stream) != hipSuccess) goto out;
+    if (edge_rows) h_off[n_full + 1] = words + words_e;  /* h_off[n_full] == words (or 0 without full chunks) */
     s.t_pcie = now() - t0;
 
     t0 = now();
@@ -201,7 +238,10 @@ out:
     if (f >= 0) { if (H5Fclose(f) < 0 && rc == DRX_OK) rc = DRX_ERR_ARG; }
     s.t_file = now() - t0;
     if (plan) drx_plan_destroy(plan);
+    if (plan_edge) drx_plan_destroy(plan_edge);
     if (d_words) (void)hipFree(d_words);
+    if (d_words_e) (void)hipFree(d_words_e);
+    if (d_edge) (void)hipFree(d_edge);
     if (d_off) (void)hipFree(d_off);
     if (h_words) (void)hipHostFree(h_words);
     free(h_off);

@@ -2,7 +2,7 @@
 """Randomised parity sweep on the GPU: random batch shapes (uniform and ragged), waveform lengths from 1 to
 hundreds of thousands, every k, several signal kinds, general filters; GPU encode must equal the oracle's
 bytes and GPU decode (default path and the variants a shape can take) must return the input.
-usage: tools/fuzz_parity.py [cases] [seed]"""
+usage: python tests/fuzz_parity.py [cases] [seed]   (test infrastructure: it uses the oracle)"""
 import os
 import sys
 import time

@@ -453,18 +453,18 @@ def test_few_long_waveforms_take_the_wave_per_waveform_decoder(ctx, O):
 
 
 def test_randomised_shapes_vs_oracle():
-    """tools/fuzz_parity.py with a fixed seed: random uniform / ragged batches, WaveformLength from 1 to 300 000,
+    """tests/fuzz_parity.py with a fixed seed: random uniform / ragged batches, WaveformLength from 1 to 300 000,
     every k, five signal kinds, general filters; every encoder and the decoder variants a shape can take."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "120", "11"],
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_parity.py"), "120", "11"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_segment_encoder_units_past_a_short_last_waveform(ctx, O):
-    """Regression (found by tools/fuzz_parity.py): a chunk of 400 000 samples at WaveformLength 300 000 has a last
+    """Regression (found by tests/fuzz_parity.py): a chunk of 400 000 samples at WaveformLength 300 000 has a last
     waveform of 100 000 samples; the segment encoder's units past its end once read the sample in front of a
     segment that does not exist -- out of bounds."""
     x = np.zeros(400_000, np.int16)

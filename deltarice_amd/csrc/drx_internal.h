@@ -43,6 +43,7 @@ struct Geom {
                    //             4 request pieces without counting on the round's minimum consumption
                    //             8 walk with vector loads, 64 chunks per wave (the pre-scalar-load walk)
                    //           256 never take the long-waveform paths   512 long waveforms: one workgroup per waveform only
+                   //          2048 never take the parallel header walk of small batches
                    //   encode:  16 per-code LDS emission instead of the lane-local concatenation
                    //            32 no emission   64 no copy-out   128 no look-back (positions wrong)
     // ragged batches, walk inside the decode launch: chunk indices, short-waveform chunks first
@@ -86,7 +87,8 @@ hipError_t launch_encode_long(const Geom &G, const int16_t *d_in, uint32_t *d_ou
 hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                          const uint64_t *d_chunk_word_off, int16_t *d_out, uint64_t *d_wave_off,
                          uint32_t *d_wave_words, uint64_t *d_granules, DevStatus *d_status, int impl,
-                         uint64_t *d_long, hipEvent_t *ev, hipStream_t s);
+                         uint64_t *d_long, void *d_pw, hipEvent_t *ev, hipStream_t s);
+uint64_t par_walk_scratch_bytes(const Geom &G);
 // scratch of the workgroup-per-block decoder of a handful of long waveforms (0: that path is not taken)
 uint64_t long_decode_scratch_bytes(const Geom &G);
 constexpr uint32_t kWalkShortLenHost = 2048;  // keep equal to kWalkShortLen in drx_kernels.hip

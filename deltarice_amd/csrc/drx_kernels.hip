@@ -1062,12 +1062,16 @@ __device__ __forceinline__ void walk_chunks_scalar(const Geom &G, uint64_t c0, c
                                                    uint64_t n_list, const uint32_t *__restrict__ in,
                                                    uint64_t in_words, const uint64_t *__restrict__ chunk_word_off,
                                                    uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
-                                                   uint64_t *__restrict__ granules, DevStatus *st) {
-    // lanes 0..kWalkChains-1 take entries c0.. of the chunk list (list == nullptr: chunk index = entry)
+                                                   uint64_t *__restrict__ granules, DevStatus *st,
+                                                   const uint32_t *__restrict__ only = nullptr) {
+    // lanes 0..kWalkChains-1 take entries c0.. of the chunk list (list == nullptr: chunk index = entry);
+    // only != nullptr: just the chunks it flags (the ones k_walk_parallel gave up on)
     const int lane = lane_id();
     const uint64_t e = c0 + (uint64_t)lane;
-    const bool mine = lane < kWalkChains && e < n_list;
+    bool mine = lane < kWalkChains && e < n_list;
     const uint64_t c = mine ? (list ? (uint64_t)list[e] : e) : 0;
+    if (only && mine && !only[c]) mine = false;
+    if (only && !__any(mine)) return;
     uint32_t W = 0, L = 1, N = 0;
     uint64_t base = 0;
     if (mine) {
@@ -1155,6 +1159,198 @@ __global__ __launch_bounds__(64) void k_walk_scalar(Geom G, const uint32_t *__re
                                                     DevStatus *st) {
     walk_chunks_scalar(G, (uint64_t)blockIdx.x * kWalkChains, nullptr, G.n_chunks, in, in_words, chunk_word_off, wave_off,
                        wave_words, nullptr, st);
+}
+
+__global__ __launch_bounds__(64) void k_walk_scalar_only(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
+                                                         const uint64_t *__restrict__ chunk_word_off,
+                                                         uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
+                                                         DevStatus *st, const uint32_t *__restrict__ only) {
+    walk_chunks_scalar(G, (uint64_t)blockIdx.x * kWalkChains, nullptr, G.n_chunks, in, in_words, chunk_word_off, wave_off,
+                       wave_words, nullptr, st, only);
+}
+
+// The header chain WITHOUT its 2000 dependent round trips, for batches of a handful of chunks (where nothing hides
+// them: 1.7 ms of a 2.2 ms decode).  A length header is a small number (n_i <= 25 bits per sample: 5469 for
+// L = 7000) and payload words are Rice-coded bits, which practically never start with 19 zero bits.  So:
+//   1. the whole chunk is read once (k_pw_scan, 16 workgroups per chunk) and every word <= that bound becomes a
+//      CANDIDATE header (the ~2000 real ones plus a few impostors); one workgroup per chunk sorts them by position;
+//   2. candidate i links to the candidate at position pos_i + n_i + 1 (binary search), to END if that is the chunk
+//      end, to INVALID if no candidate sits there;
+//   3. binary lifting over those links (up[k][i] = 2^k links ahead), then waveform w's header is w links from the
+//      candidate at word 1: eleven steps, every waveform in parallel.  Impostors are simply never reached.
+// Anything unexpected (too many candidates, a broken link, a chain that does not end at the chunk end) flags the
+// chunk, and the scalar-load walker walks -- and judges -- the flagged chunks afterwards.
+constexpr int kPwThreads = 1024;
+constexpr uint32_t kPwCap = 4096;      // candidates per chunk, a power of two (bitonic sort)
+constexpr int kPwLevels = 12;
+constexpr uint32_t kPwMaxWaves = 3584;  // waveforms per chunk this kernel takes (leaves room for impostors)
+constexpr uint64_t kPwMaxChunks = 224;   // batches with more chunks hide the serial walk behind the decoding
+
+constexpr uint32_t kPwParts = 16;  // workgroups that scan one chunk
+
+// 1. candidates of one slice of a chunk -> the chunk's list in global memory (cand: kPwCap x {pos, val} per chunk,
+//    cand_count: one counter per chunk, zeroed before the launch)
+__global__ __launch_bounds__(256) void k_pw_scan(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
+                                                 const uint64_t *__restrict__ chunk_word_off, uint2 *__restrict__ cand,
+                                                 uint32_t *__restrict__ cand_count) {
+    const uint64_t c = blockIdx.x / kPwParts;
+    const uint32_t part = blockIdx.x % kPwParts, tid = threadIdx.x;
+    const uint64_t begin = chunk_word_off[c], end = chunk_word_off[c + 1];
+    if (end > in_words || begin + 2 > end || end - begin > 0x7fffffffull) return;  // k_walk_parallel flags the chunk
+    const uint32_t len_w = (uint32_t)(end - begin);
+    const uint32_t max_full = (uint32_t)(((uint64_t)G.u_wave_len * 25u + 31u) >> 5);
+    uint2 *list = cand + c * kPwCap;
+    // the slice's candidates are collected in LDS and appended with ONE global atomic (2000 atomics on one counter
+    // cost 0.2 ms: same-address atomics serialise in the L2)
+    __shared__ uint2 s_list[kPwCap / 4];
+    __shared__ uint32_t s_n, s_base;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    auto consider = [&](uint32_t i, uint32_t v) __attribute__((always_inline)) {
+        if (i >= 1u && i < len_w && v <= max_full) {
+            const uint32_t k = atomicAdd(&s_n, 1u);
+            if (k < kPwCap / 4) s_list[k] = make_uint2(i, v);
+        }
+    };
+    // 16-byte loads, four in flight per thread (a dependent 4-byte load per word made this pass take as long as
+    // the serial walk it replaces); quads are aligned, the first one may start below the chunk
+    const uint32_t mis = (uint32_t)((((uintptr_t)in >> 2) + begin) & 3u);
+    const uint32_t *q0 = in + begin - mis;  // words before `begin` are ignored by consider()
+    const uint32_t n_quads = (len_w + mis + 3u) >> 2;
+    const bool vec_ok = begin >= mis;
+    const uint32_t per = (n_quads + kPwParts - 1u) / kPwParts;
+    const uint32_t q_lo = part * per, q_hi = (q_lo + per < n_quads) ? q_lo + per : n_quads;
+    constexpr uint32_t U = 4;
+    for (uint32_t qb = q_lo + tid; qb < q_hi; qb += 256u * U) {
+        uint4 v[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t qi = qb + u * 256u;
+            v[u] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+            if (qi < q_hi) {
+                const uint64_t w0 = begin - mis + 4ull * qi;  // absolute word index of the quad
+                if (vec_ok && w0 + 4u <= in_words) {
+                    v[u] = *reinterpret_cast<const uint4 *>(q0 + 4ull * qi);
+                } else {
+                    if (w0 + 0u < in_words && w0 + 0u >= begin) v[u].x = in[w0 + 0u];
+                    if (w0 + 1u < in_words && w0 + 1u >= begin) v[u].y = in[w0 + 1u];
+                    if (w0 + 2u < in_words && w0 + 2u >= begin) v[u].z = in[w0 + 2u];
+                    if (w0 + 3u < in_words && w0 + 3u >= begin) v[u].w = in[w0 + 3u];
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t i0 = 4u * (qb + u * 256u) - mis;  // may wrap below zero for the first quad: consider() rejects
+            consider(i0 + 0u, v[u].x);
+            consider(i0 + 1u, v[u].y);
+            consider(i0 + 2u, v[u].z);
+            consider(i0 + 3u, v[u].w);
+        }
+    }
+    __syncthreads();
+    const uint32_t n_loc = s_n;
+    if (n_loc > kPwCap / 4) {  // more candidates in one slice than a sane chunk has in four: let the serial walker judge
+        if (tid == 0) atomicAdd(cand_count + c, kPwCap);
+        return;
+    }
+    if (tid == 0) s_base = atomicAdd(cand_count + c, n_loc);
+    __syncthreads();
+    const uint32_t b0 = s_base;
+    for (uint32_t i = tid; i < n_loc; i += 256u)
+        if (b0 + i < kPwCap) list[b0 + i] = s_list[i];
+}
+
+__global__ __launch_bounds__(kPwThreads) void k_walk_parallel(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
+                                                              const uint64_t *__restrict__ chunk_word_off,
+                                                              uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
+                                                              uint32_t *__restrict__ fail, const uint2 *__restrict__ cand,
+                                                              const uint32_t *__restrict__ cand_count) {
+    __shared__ uint32_t pos[kPwCap];   // candidate positions relative to the chunk start; padding entries sort last
+    __shared__ uint32_t val[kPwCap];
+    __shared__ uint16_t up[kPwLevels][kPwCap];
+    __shared__ uint32_t s_bad, s_start;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t c = blockIdx.x;
+    const uint32_t W = G.u_n_waves, L = G.u_wave_len, N = G.u_n_samples;
+    const uint64_t base = c * W;
+    const uint64_t begin = chunk_word_off[c];
+    const uint64_t end = chunk_word_off[c + 1];
+    if (tid == 0) { s_bad = 0; s_start = 0xffffffffu; }
+    __syncthreads();
+    bool ok = !(end > in_words || begin + 2 > end || end - begin > 0x7fffffffull);
+    if (ok && in[begin] != N) ok = false;
+    if (!ok) { if (tid == 0) fail[c] = 1u; return; }  // (uniform across the workgroup)
+    const uint32_t len_w = (uint32_t)(end - begin);  // words in the chunk
+    const uint32_t max_full = (uint32_t)(((uint64_t)L * 25u + 31u) >> 5);
+    const uint32_t max_last = (uint32_t)(((uint64_t)(N - (W - 1) * L) * 25u + 31u) >> 5);
+    const uint32_t nc = cand_count[c];
+    if (nc > kPwCap - 2u || nc < W) { if (tid == 0) fail[c] = 1u; return; }
+    for (uint32_t i = tid; i < kPwCap; i += kPwThreads) {
+        const uint2 e = i < nc ? cand[c * kPwCap + i] : make_uint2(0xffffffffu, 0u);
+        pos[i] = e.x;
+        val[i] = e.y;
+    }
+    __syncthreads();
+    // sort by position (bitonic, kPwCap elements, two compare-exchanges per thread and stage)
+    for (uint32_t k2 = 2; k2 <= kPwCap; k2 <<= 1) {
+        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < kPwCap / 2; t += kPwThreads) {
+                const uint32_t a = ((t & ~(j - 1u)) << 1) | (t & (j - 1u));  // index with bit log2(j) clear
+                const uint32_t b = a | j;
+                const bool asc = (a & k2) == 0;
+                const uint32_t pa = pos[a], pb = pos[b];
+                if ((pa > pb) == asc) {
+                    pos[a] = pb; pos[b] = pa;
+                    const uint32_t va = val[a]; val[a] = val[b]; val[b] = va;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // 2. links.  Nodes nc (END) and nc + 1 (INVALID) point to themselves.
+    const uint32_t END = nc, INV = nc + 1u;
+    for (uint32_t i = tid; i < kPwCap; i += kPwThreads) {
+        uint32_t to = i;  // padding and the two sentinels: self loops
+        if (i < nc) {
+            const uint64_t target = (uint64_t)pos[i] + val[i] + 1u;
+            if (target == len_w) {
+                to = END;
+            } else if (target > len_w) {
+                to = INV;
+            } else {
+                uint32_t lo = 0, hi = nc;  // first candidate with pos >= target
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (pos[mid] < (uint32_t)target) lo = mid + 1u; else hi = mid; }
+                to = (lo < nc && pos[lo] == (uint32_t)target) ? lo : INV;
+            }
+            if (pos[i] == 1u) s_start = i;  // the first waveform's header follows the chunk header
+        }
+        up[0][i] = (uint16_t)to;
+    }
+    __syncthreads();
+    // 3. binary lifting
+    for (int k = 1; k < kPwLevels; ++k) {
+        for (uint32_t i = tid; i < kPwCap; i += kPwThreads) up[k][i] = up[k - 1][up[k - 1][i]];
+        __syncthreads();
+    }
+    const uint32_t start = s_start;
+    if (start == 0xffffffffu) { if (tid == 0) fail[c] = 1u; return; }
+    bool bad = false;
+    for (uint32_t w = tid; w < W; w += kPwThreads) {
+        uint32_t node = start;
+#pragma unroll
+        for (int k = 0; k < kPwLevels; ++k)
+            if ((w >> k) & 1u) node = up[k][node];
+        if (node >= nc) { bad = true; continue; }
+        const uint32_t n = val[node];
+        if (n > ((w + 1u == W) ? max_last : max_full)) { bad = true; continue; }
+        if (w + 1u == W && up[0][node] != END) { bad = true; continue; }
+        wave_off[base + w] = begin + pos[node];
+        wave_words[base + w] = n;
+    }
+    if (bad) atomicOr(&s_bad, 1u);
+    __syncthreads();
+    if (tid == 0 && s_bad) fail[c] = 1u;
 }
 
 __global__ __launch_bounds__(64) void k_walk(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
@@ -2144,6 +2340,12 @@ uint64_t long_decode_scratch_bytes(const Geom &G) {
 // single-pass encoder pays a workgroup barrier, a look-back and an 8 KB LDS clear per 512-2048 samples
 // (200 chunks of 14 M samples: L = 512 0.57 -> 0.95 TB/s, 1024 0.97 -> 1.33, 2048 1.51 -> 1.68; 7000 is better off
 // with the single pass)
+// scratch of the parallel header walk (0: the batch does not take it)
+uint64_t par_walk_scratch_bytes(const Geom &G) {
+    if (!(G.uniform && G.n_chunks <= kPwMaxChunks && G.u_n_waves <= kPwMaxWaves && G.u_n_waves >= 64u && G.u_wave_len > kWalkShortLen)) return 0;
+    return G.n_chunks * (kPwCap * sizeof(uint2) + 2u * sizeof(uint32_t));
+}
+
 bool long_batch(const Geom &G) {
     if (G.n_taps) return false;
     if (!G.uniform) return G.seg_unit_base != nullptr;  // decided when the plan was made (some chunk is short or long)
@@ -2177,7 +2379,7 @@ hipError_t launch_encode_long(const Geom &G, const int16_t *d_in, uint32_t *d_ou
 hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                          const uint64_t *d_chunk_word_off, int16_t *d_out, uint64_t *d_wave_off,
                          uint32_t *d_wave_words, uint64_t *d_granules, DevStatus *d_status, int impl,
-                         uint64_t *d_long, hipEvent_t *ev, hipStream_t s) {
+                         uint64_t *d_long, void *d_pw, hipEvent_t *ev, hipStream_t s) {
     if (G.total_waves == 0) return hipSuccess;
     mark(ev, 0, s);
     // impl >= 100: wave_off / wave_words are already filled in (the one-chunk host path walks the header
@@ -2198,9 +2400,12 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
     // ragged: the group-major grid has max_groups tickets per chunk; not when most of them would be idle
     // few long waveforms (delta filter): a wavefront per waveform instead of a lane per waveform
     const bool long_path = !gen && impl != 0 && !(G.dbg & 256u) && G.uniform && long_waveform_batch(G.total_waves, G.u_wave_len);
+    // a handful of chunks of long-enough waveforms: the parallel walk, then a plain decode launch
+    const bool par_walk = d_pw && !tables_ready && !(G.dbg & 2048u) && G.uniform && G.n_chunks <= kPwMaxChunks &&
+                          G.u_n_waves <= kPwMaxWaves && G.u_n_waves >= 64u && G.u_wave_len > kWalkShortLen;
     const bool sparse = !G.uniform && (uint64_t)G.n_chunks * G.max_groups > 8ull * ((G.total_waves + 63u) / 64u) + 4096ull;
     const bool fused = (impl == 5 || impl == 6 || impl == 8 || impl == 14 || impl == 15 || impl == 17) && (!needs_block || big_ring) &&
-                       !((G.dbg & 8u) && needs_block) && !sparse && !long_path;  // the in-launch walk needs the arithmetic chunk mapping
+                       !((G.dbg & 8u) && needs_block) && !sparse && !long_path && !par_walk;  // the in-launch walk needs the arithmetic chunk mapping
     if (fused) {
         // granules + ticket word, zeroed before every launch (a granule is its own ready flag)
         hipError_t e = hipMemsetAsync(d_granules, 0, (G.total_waves + 2) * sizeof(uint64_t), s);
@@ -2229,6 +2434,19 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
     } else {
         // chunks of short waveforms: stream the chunk through LDS; long waveforms: one dependent load per hop
         if (tables_ready) {
+        } else if (par_walk) {
+            // scratch: uint2 cand[n_chunks * kPwCap] | uint32 count[n_chunks] | uint32 fail[n_chunks]
+            uint2 *cand = reinterpret_cast<uint2 *>(d_pw);
+            uint32_t *cnt = reinterpret_cast<uint32_t *>(cand + G.n_chunks * kPwCap), *d_pw_fail = cnt + G.n_chunks;
+            hipError_t e = hipMemsetAsync(cnt, 0, 2u * G.n_chunks * sizeof(uint32_t), s);
+            if (e != hipSuccess) return e;
+            k_pw_scan<<<(unsigned)(G.n_chunks * kPwParts), 256, 0, s>>>(G, d_in, in_words, d_chunk_word_off, cand, cnt);
+            k_walk_parallel<<<(unsigned)G.n_chunks, kPwThreads, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words,
+                                                                        d_pw_fail, cand, cnt);
+            k_walk_scalar_only<<<blocks_for(G.n_chunks, kWalkChains), 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off,
+                                                                                  d_wave_words, d_status, d_pw_fail);
+            if (impl == 5) impl = 1;
+            if (impl == 8 || impl == 14 || impl == 15 || impl == 17) impl = 7;
         } else if (G.uniform) {
             if (G.u_wave_len <= kWalkShortLen)
                 k_walk_block<<<(unsigned)G.n_chunks, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, nullptr,

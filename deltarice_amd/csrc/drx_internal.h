@@ -89,6 +89,7 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                          uint32_t *d_wave_words, uint64_t *d_granules, DevStatus *d_status, int impl,
                          uint64_t *d_long, void *d_pw, hipEvent_t *ev, hipStream_t s);
 uint64_t par_walk_scratch_bytes(const Geom &G);
+uint32_t bw_walk_blocks_max(const Geom &G);
 // scratch of the workgroup-per-block decoder of a handful of long waveforms (0: that path is not taken)
 uint64_t long_decode_scratch_bytes(const Geom &G);
 constexpr uint32_t kWalkShortLenHost = 2048;  // keep equal to kWalkShortLen in drx_kernels.hip

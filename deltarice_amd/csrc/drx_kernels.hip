@@ -1489,6 +1489,191 @@ __global__ __launch_bounds__(64) void k_walk_block(Geom G, const uint32_t *__res
     walk_chunk_block(G, c, in, in_words, chunk_word_off, wave_off, wave_words, nullptr, st, blk, hop);
 }
 
+// The same idea for chunks of SHORT waveforms (tens of thousands of headers per chunk: too many for one
+// workgroup's LDS, and the chain chase through LDS still costs 0.13 us per hop, 3.6 ms for 14 M samples at
+// L = 512).  A header is at most max_words = 25 L / 32 (400 for L = 512) and every 4096-word block of the stream
+// holds several of them, so the BLOCKS become independent: a wavefront loads its block, takes the first word <=
+// max_words as the block's entry header, chases the chain through LDS to the block's end (if the chain breaks,
+// the entry was an impostor: try the next small word), and reports {entry, headers, exit}.  k_bw_scan checks per
+// chunk that every block's exit is the next block's entry (and word 1 / the chunk end at the two ends) and
+// turns the counts into first-waveform indices; k_bw_blocks then runs again and writes the table.  A chunk
+// that does not stitch is flagged and walked by k_walk_block.
+constexpr uint32_t kBwTries = 6;  // impostors tolerated in front of a block's first real header
+
+struct BwBlock { uint32_t entry, count, exit, base; };
+
+template <bool EMIT>
+__global__ __launch_bounds__(64) void k_bw_blocks(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
+                                                  const uint64_t *__restrict__ chunk_word_off, uint32_t blocks_max,
+                                                  BwBlock *__restrict__ info, const uint32_t *__restrict__ fail,
+                                                  uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
+                                                  DevStatus *st) {
+    constexpr uint32_t B = kWalkBlockWords;
+    constexpr int NV = B / 256;
+    __shared__ __attribute__((aligned(16))) uint32_t blk[B];
+    __shared__ __attribute__((aligned(8))) uint2 hop[kWalkHopCap];
+    const int lane = lane_id();
+    const uint64_t unit = blockIdx.x;
+    const uint64_t c = unit / blocks_max;
+    const uint32_t b = (uint32_t)(unit - c * blocks_max);
+    if (c >= G.n_chunks) return;
+    if (EMIT && fail[c]) return;
+    const uint32_t W = G.u_n_waves, L = G.u_wave_len;
+    const uint64_t begin = chunk_word_off[c], end = chunk_word_off[c + 1];
+    if (end > in_words || begin + 2 > end || end - begin > 0x7fffffffull) return;  // k_bw_scan flags the chunk
+    const uint32_t len_w = (uint32_t)(end - begin);
+    const uint32_t b0 = b * B;  // block = words [b0, b0 + B) of the chunk
+    if (b0 >= len_w) return;
+    const uint32_t blk_len = len_w - b0 < B ? len_w - b0 : B;
+    const uint32_t max_full = (uint32_t)(((uint64_t)L * 25u + 31u) >> 5);
+    // the block's words into LDS (the same fixed grid of 16-byte quads as walk_chunk_block, relative to the chunk)
+    {
+        const uint64_t a0 = begin + b0;
+        const bool vec_ok = (((uintptr_t)(in + a0)) & 15u) == 0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const uint32_t i = (uint32_t)(j * 64 + lane) * 4u;
+            uint4 v;
+            if (vec_ok && i + 4u <= blk_len) {
+                v = *reinterpret_cast<const uint4 *>(in + a0 + i);
+            } else {
+                v.x = (i + 0u < blk_len) ? in[a0 + i + 0u] : 0xffffffffu;
+                v.y = (i + 1u < blk_len) ? in[a0 + i + 1u] : 0xffffffffu;
+                v.z = (i + 2u < blk_len) ? in[a0 + i + 2u] : 0xffffffffu;
+                v.w = (i + 3u < blk_len) ? in[a0 + i + 3u] : 0xffffffffu;
+            }
+            *reinterpret_cast<uint4 *>(blk + i) = v;
+        }
+    }
+    wave_sync();
+    uint32_t entry, count = 0, exit_pos = 0;
+    bool found = false;
+    if (EMIT) {
+        entry = info[unit].entry;
+        if (entry == 0xffffffffu) return;  // a last block without a header (k_bw_scan)
+        found = true;
+    } else {
+        // candidates in position order: the first word <= max_words at or after `from` (word 0 of the chunk is its
+        // sample count: block 0 starts at word 1)
+        uint32_t from = b == 0 ? 1u : 0u;
+        entry = 0xffffffffu;
+        for (uint32_t t = 0; t < kBwTries && !found; ++t) {
+            uint32_t first = 0xffffffffu;
+            for (uint32_t i = (uint32_t)lane; i < blk_len; i += 64u) {  // lane-strided: the first hit of a lane is its smallest
+                // (never 0: a waveform has at least one payload word, while the zero-padded LAST word of a waveform is
+                // all zeros whenever its final code ends in zero bits -- an impostor that would chain straight into
+                // the real header behind it)
+                if (i >= from && blk[i] - 1u < max_full) { first = i; break; }
+            }
+            first = ~wave_max_u32(~first);  // minimum over the wave
+            if (first == 0xffffffffu) break;
+            // chase from `first` to the block's end
+            uint32_t rel = first, cnt = 0;
+            bool ok = true;
+            while (rel < blk_len) {
+                const uint32_t n = __builtin_amdgcn_readfirstlane(blk[rel]);
+                if (n > max_full || (uint64_t)b0 + rel + 1u + n > len_w) { ok = false; break; }
+                rel += n + 1u;
+                ++cnt;
+            }
+            if (ok) { found = true; entry = first; count = cnt; exit_pos = b0 + rel; }
+            else from = first + 1u;
+        }
+        if (lane == 0) {
+            BwBlock o;
+            o.entry = found ? b0 + entry : 0xffffffffu;
+            o.count = count;
+            o.exit = exit_pos;
+            o.base = 0;
+            info[unit] = o;
+        }
+        return;
+    }
+    // EMIT: chase again from the accepted entry, writing the table
+    const uint64_t base = c * W + info[unit].base;
+    uint32_t rel = entry - b0, w = 0;
+    while (rel < blk_len) {
+        uint32_t hops = 0;
+        const uint32_t w0 = w;
+        while (rel < blk_len && hops < kWalkHopCap) {
+            const uint32_t n = __builtin_amdgcn_readfirstlane(blk[rel]);
+            hop[hops] = make_uint2(rel, n);
+            rel += n + 1u;
+            ++w;
+            ++hops;
+        }
+        wave_sync();
+        for (uint32_t i = lane; i < hops; i += 64) {
+            const uint2 h = hop[i];
+            wave_off[base + w0 + i] = begin + b0 + h.x;
+            wave_words[base + w0 + i] = h.y;
+            // the chunk's last waveform may be shorter than the rest: its header has a tighter bound
+            if (info[unit].base + w0 + i + 1u == W) {
+                const uint32_t max_last = (uint32_t)(((uint64_t)(G.u_n_samples - (W - 1u) * L) * 25u + 31u) >> 5);
+                if (h.y > max_last) atomicOr(&st->err, kErrCorrupt);
+            }
+        }
+        wave_sync();
+    }
+}
+
+// one wavefront per chunk: stitch the blocks, first-waveform index of every block, verdict
+__global__ __launch_bounds__(64) void k_bw_scan(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
+                                                const uint64_t *__restrict__ chunk_word_off, uint32_t blocks_max,
+                                                BwBlock *__restrict__ info, uint32_t *__restrict__ fail) {
+    const int lane = lane_id();
+    const uint64_t c = blockIdx.x;
+    const uint32_t W = G.u_n_waves, L = G.u_wave_len, N = G.u_n_samples;
+    const uint64_t begin = chunk_word_off[c], end = chunk_word_off[c + 1];
+    bool bad = end > in_words || begin + 2 > end || end - begin > 0x7fffffffull;
+    if (!bad && in[begin] != N) bad = true;
+    const uint32_t len_w = bad ? 0u : (uint32_t)(end - begin);
+    const uint32_t n_blocks = (len_w + kWalkBlockWords - 1u) / kWalkBlockWords;
+    if (n_blocks > blocks_max) bad = true;
+    BwBlock *my = info + c * blocks_max;
+    uint32_t run = 0;
+    for (uint32_t b0 = 0; b0 < n_blocks && !bad; b0 += 64) {
+        const uint32_t b = b0 + (uint32_t)lane;
+        BwBlock o{0xffffffffu, 0, 0, 0};
+        if (b < n_blocks) o = my[b];
+        // every block must have been entered, start where its predecessor left, and the ends must be the chunk's
+        uint32_t prev_exit = (uint32_t)__shfl_up((int)o.exit, 1);
+        if (lane == 0) prev_exit = b0 ? my[b0 - 1u].exit : 1u;
+        bool lane_bad = false;
+        if (b < n_blocks) {
+            if (b + 1u == n_blocks && b > 0u && prev_exit == len_w) {
+                // the chain already ended inside the previous block: the last block is the tail of the last payload and
+                // has no header of its own (whatever small word it may hold is not one)
+                o.count = 0;
+                my[b].entry = 0xffffffffu;
+                my[b].count = 0;
+            } else {
+                lane_bad = o.entry == 0xffffffffu || o.entry != prev_exit;
+                if (b + 1u == n_blocks && o.exit != len_w) lane_bad = true;
+            }
+        }
+        if (__any(lane_bad)) { bad = true; break; }
+        const uint32_t inc = wave_incl_scan_dpp(b < n_blocks ? o.count : 0u);
+        if (b < n_blocks) my[b].base = run + inc - o.count;
+        run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    }
+    if (!bad && run != W) bad = true;
+    // the last waveform may be shorter: its header has a tighter bound than the blocks checked
+    if (lane == 0) fail[c] = bad ? 1u : 0u;
+    (void)L;
+}
+
+__global__ __launch_bounds__(64) void k_walk_block_only(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
+                                                        const uint64_t *__restrict__ chunk_word_off,
+                                                        uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
+                                                        DevStatus *st, const uint32_t *__restrict__ only) {
+    __shared__ __attribute__((aligned(16))) uint32_t blk[kWalkBlockWords];
+    __shared__ __attribute__((aligned(8))) uint2 hop[kWalkHopCap];
+    const uint64_t c = blockIdx.x;
+    if (c >= G.n_chunks || !only[c]) return;
+    walk_chunk_block(G, c, in, in_words, chunk_word_off, wave_off, wave_words, nullptr, st, blk, hop);
+}
+
 // Straightforward lane-per-waveform decoder: global loads and 2-byte stores.
 // Kept as the simple cross-check of the staged kernel below (decode_impl = 0).
 __global__ __launch_bounds__(64) void k_decode_simple(Geom G, const uint32_t *__restrict__ in,
@@ -2340,8 +2525,20 @@ uint64_t long_decode_scratch_bytes(const Geom &G) {
 // single-pass encoder pays a workgroup barrier, a look-back and an 8 KB LDS clear per 512-2048 samples
 // (200 chunks of 14 M samples: L = 512 0.57 -> 0.95 TB/s, 1024 0.97 -> 1.33, 2048 1.51 -> 1.68; 7000 is better off
 // with the single pass)
-// scratch of the parallel header walk (0: the batch does not take it)
+// block-parallel walk of short waveforms: blocks per chunk at 25 bits per sample (0: the batch does not take it)
+uint32_t bw_walk_blocks_max(const Geom &G) {
+    // the two block passes cost ~15 us per chunk, the serial chase ~0.13 us per waveform of a chunk (all chunks at
+    // once) and large batches hide most of it: measured crossovers 150 chunks at L = 512, 80 at L = 2048
+    const uint64_t limit = G.u_n_waves / 100u < 150u ? G.u_n_waves / 100u : 150u;
+    if (!(G.uniform && G.n_chunks <= limit && G.u_wave_len <= kWalkShortLen && G.u_wave_len >= 16u)) return 0;
+    const uint64_t max_words = 1u + G.u_n_waves + (((uint64_t)G.u_n_samples * 25u + 31u) >> 5) + G.u_n_waves;
+    const uint64_t nb = (max_words + kWalkBlockWords - 1u) / kWalkBlockWords;
+    return nb > 0xfffffu ? 0u : (uint32_t)nb;
+}
+
+// scratch of the parallel header walks (0: the batch takes neither)
 uint64_t par_walk_scratch_bytes(const Geom &G) {
+    if (const uint32_t nb = bw_walk_blocks_max(G)) return G.n_chunks * ((uint64_t)nb * sizeof(BwBlock) + sizeof(uint32_t));
     if (!(G.uniform && G.n_chunks <= kPwMaxChunks && G.u_n_waves <= kPwMaxWaves && G.u_n_waves >= 64u && G.u_wave_len > kWalkShortLen)) return 0;
     return G.n_chunks * (kPwCap * sizeof(uint2) + 2u * sizeof(uint32_t));
 }
@@ -2403,9 +2600,12 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
     // a handful of chunks of long-enough waveforms: the parallel walk, then a plain decode launch
     const bool par_walk = d_pw && !tables_ready && !(G.dbg & 2048u) && G.uniform && G.n_chunks <= kPwMaxChunks &&
                           G.u_n_waves <= kPwMaxWaves && G.u_n_waves >= 64u && G.u_wave_len > kWalkShortLen;
+    // ... and of short waveforms: the block-parallel walk
+    const uint32_t bw_blocks_max = bw_walk_blocks_max(G);
+    const bool bw_walk = d_pw && bw_blocks_max && !tables_ready && !(G.dbg & 2048u);
     const bool sparse = !G.uniform && (uint64_t)G.n_chunks * G.max_groups > 8ull * ((G.total_waves + 63u) / 64u) + 4096ull;
     const bool fused = (impl == 5 || impl == 6 || impl == 8 || impl == 14 || impl == 15 || impl == 17) && (!needs_block || big_ring) &&
-                       !((G.dbg & 8u) && needs_block) && !sparse && !long_path && !par_walk;  // the in-launch walk needs the arithmetic chunk mapping
+                       !((G.dbg & 8u) && needs_block) && !sparse && !long_path && !par_walk && !bw_walk;  // the in-launch walk needs the arithmetic chunk mapping
     if (fused) {
         // granules + ticket word, zeroed before every launch (a granule is its own ready flag)
         hipError_t e = hipMemsetAsync(d_granules, 0, (G.total_waves + 2) * sizeof(uint64_t), s);
@@ -2445,6 +2645,17 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                                                                         d_pw_fail, cand, cnt);
             k_walk_scalar_only<<<blocks_for(G.n_chunks, kWalkChains), 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off,
                                                                                   d_wave_words, d_status, d_pw_fail);
+            if (impl == 5) impl = 1;
+            if (impl == 8 || impl == 14 || impl == 15 || impl == 17) impl = 7;
+        } else if (bw_walk) {
+            // scratch: BwBlock info[n_chunks * blocks_max] | uint32 fail[n_chunks]
+            BwBlock *info = reinterpret_cast<BwBlock *>(d_pw);
+            const uint64_t units = G.n_chunks * bw_blocks_max;
+            uint32_t *bw_fail = reinterpret_cast<uint32_t *>(info + units);
+            k_bw_blocks<false><<<(unsigned)units, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, bw_blocks_max, info, nullptr, nullptr, nullptr, d_status);
+            k_bw_scan<<<(unsigned)G.n_chunks, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, bw_blocks_max, info, bw_fail);
+            k_bw_blocks<true><<<(unsigned)units, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, bw_blocks_max, info, bw_fail, d_wave_off, d_wave_words, d_status);
+            k_walk_block_only<<<(unsigned)G.n_chunks, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_status, bw_fail);
             if (impl == 5) impl = 1;
             if (impl == 8 || impl == 14 || impl == 15 || impl == 17) impl = 7;
         } else if (G.uniform) {

@@ -54,6 +54,9 @@ struct Geom {
     // segment slot) of every chunk, n_chunks + 1 entries, and their total
     const uint64_t *seg_unit_base;
     uint64_t seg_units;
+    // ragged batches small enough for the parallel header walks (drx_kernels.hip): set when the plan is made;
+    // rag_bw_blocks_max = 4096-word blocks of the largest short-waveform chunk at 25 bits per sample
+    uint32_t rag_par, rag_bw_blocks_max;
 };
 
 struct DevStatus {
@@ -93,6 +96,10 @@ uint32_t bw_walk_blocks_max(const Geom &G);
 // scratch of the workgroup-per-block decoder of a handful of long waveforms (0: that path is not taken)
 uint64_t long_decode_scratch_bytes(const Geom &G);
 constexpr uint32_t kWalkShortLenHost = 2048;  // keep equal to kWalkShortLen in drx_kernels.hip
+// limits of the parallel header walks (see k_walk_parallel / k_bw_blocks)
+constexpr uint32_t kPwMaxWaves = 3584;   // waveforms per chunk the chunk-wide walk takes (leaves room for impostors)
+constexpr uint64_t kPwMaxChunks = 224;   // more chunks hide the serial walk behind the decoding, and reading the stream
+                                        // a second time costs more than it saves (measured crossover: ~260 chunks of 2000 x 7000)
 
 }  // namespace drx
 #endif

@@ -1183,23 +1183,23 @@ __global__ __launch_bounds__(64) void k_walk_scalar_only(Geom G, const uint32_t 
 constexpr int kPwThreads = 1024;
 constexpr uint32_t kPwCap = 4096;      // candidates per chunk, a power of two (bitonic sort)
 constexpr int kPwLevels = 12;
-constexpr uint32_t kPwMaxWaves = 3584;  // waveforms per chunk this kernel takes (leaves room for impostors)
-constexpr uint64_t kPwMaxChunks = 224;   // batches with more chunks hide the serial walk behind the decoding
+// (kPwMaxWaves, kPwMaxChunks: drx_internal.h)
 
 constexpr uint32_t kPwParts = 16;  // workgroups that scan one chunk
 
 // 1. candidates of one slice of a chunk -> the chunk's list in global memory (cand: kPwCap x {pos, val} per chunk,
 //    cand_count: one counter per chunk, zeroed before the launch)
 __global__ __launch_bounds__(256) void k_pw_scan(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
-                                                 const uint64_t *__restrict__ chunk_word_off, uint2 *__restrict__ cand,
-                                                 uint32_t *__restrict__ cand_count) {
-    const uint64_t c = blockIdx.x / kPwParts;
+                                                 const uint64_t *__restrict__ chunk_word_off, const uint32_t *__restrict__ list,
+                                                 uint2 *__restrict__ cand, uint32_t *__restrict__ cand_count) {
+    const uint64_t c = list ? (uint64_t)list[blockIdx.x / kPwParts] : blockIdx.x / kPwParts;  // scratch is indexed by chunk
     const uint32_t part = blockIdx.x % kPwParts, tid = threadIdx.x;
     const uint64_t begin = chunk_word_off[c], end = chunk_word_off[c + 1];
     if (end > in_words || begin + 2 > end || end - begin > 0x7fffffffull) return;  // k_walk_parallel flags the chunk
     const uint32_t len_w = (uint32_t)(end - begin);
-    const uint32_t max_full = (uint32_t)(((uint64_t)G.u_wave_len * 25u + 31u) >> 5);
-    uint2 *list = cand + c * kPwCap;
+    const uint32_t wl = G.uniform ? G.u_wave_len : G.chunks[c].wave_len;
+    const uint32_t max_full = (uint32_t)(((uint64_t)wl * 25u + 31u) >> 5);
+    uint2 *clist = cand + c * kPwCap;
     // the slice's candidates are collected in LDS and appended with ONE global atomic (2000 atomics on one counter
     // cost 0.2 ms: same-address atomics serialise in the L2)
     __shared__ uint2 s_list[kPwCap / 4];
@@ -1258,22 +1258,24 @@ __global__ __launch_bounds__(256) void k_pw_scan(Geom G, const uint32_t *__restr
     __syncthreads();
     const uint32_t b0 = s_base;
     for (uint32_t i = tid; i < n_loc; i += 256u)
-        if (b0 + i < kPwCap) list[b0 + i] = s_list[i];
+        if (b0 + i < kPwCap) clist[b0 + i] = s_list[i];
 }
 
 __global__ __launch_bounds__(kPwThreads) void k_walk_parallel(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
                                                               const uint64_t *__restrict__ chunk_word_off,
                                                               uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
-                                                              uint32_t *__restrict__ fail, const uint2 *__restrict__ cand,
-                                                              const uint32_t *__restrict__ cand_count) {
+                                                              uint32_t *__restrict__ fail, const uint32_t *__restrict__ list,
+                                                              const uint2 *__restrict__ cand, const uint32_t *__restrict__ cand_count) {
     __shared__ uint32_t pos[kPwCap];   // candidate positions relative to the chunk start; padding entries sort last
     __shared__ uint32_t val[kPwCap];
     __shared__ uint16_t up[kPwLevels][kPwCap];
     __shared__ uint32_t s_bad, s_start;
     const uint32_t tid = threadIdx.x;
-    const uint64_t c = blockIdx.x;
-    const uint32_t W = G.u_n_waves, L = G.u_wave_len, N = G.u_n_samples;
-    const uint64_t base = c * W;
+    const uint64_t c = list ? (uint64_t)list[blockIdx.x] : blockIdx.x;
+    uint32_t W, L, N;
+    uint64_t base;
+    if (G.uniform) { W = G.u_n_waves; L = G.u_wave_len; N = G.u_n_samples; base = c * W; }
+    else { const ChunkDesc d = G.chunks[c]; W = d.n_waves; L = d.wave_len; N = d.n_samples; base = d.wave_base; }
     const uint64_t begin = chunk_word_off[c];
     const uint64_t end = chunk_word_off[c + 1];
     if (tid == 0) { s_bad = 0; s_start = 0xffffffffu; }
@@ -1504,7 +1506,8 @@ struct BwBlock { uint32_t entry, count, exit, base; };
 
 template <bool EMIT>
 __global__ __launch_bounds__(64) void k_bw_blocks(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
-                                                  const uint64_t *__restrict__ chunk_word_off, uint32_t blocks_max,
+                                                  const uint64_t *__restrict__ chunk_word_off, const uint32_t *__restrict__ list,
+                                                  uint32_t n_list, uint32_t blocks_max,
                                                   BwBlock *__restrict__ info, const uint32_t *__restrict__ fail,
                                                   uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
                                                   DevStatus *st) {
@@ -1513,12 +1516,16 @@ __global__ __launch_bounds__(64) void k_bw_blocks(Geom G, const uint32_t *__rest
     __shared__ __attribute__((aligned(16))) uint32_t blk[B];
     __shared__ __attribute__((aligned(8))) uint2 hop[kWalkHopCap];
     const int lane = lane_id();
-    const uint64_t unit = blockIdx.x;
-    const uint64_t c = unit / blocks_max;
-    const uint32_t b = (uint32_t)(unit - c * blocks_max);
-    if (c >= G.n_chunks) return;
+    const uint64_t unit = blockIdx.x;          // info[] is indexed by list slot, fail[] by chunk
+    const uint64_t slot = unit / blocks_max;
+    const uint32_t b = (uint32_t)(unit - slot * blocks_max);
+    if (slot >= n_list) return;
+    const uint64_t c = list ? (uint64_t)list[slot] : slot;
     if (EMIT && fail[c]) return;
-    const uint32_t W = G.u_n_waves, L = G.u_wave_len;
+    uint32_t W, L, n_samples;
+    uint64_t wbase;
+    if (G.uniform) { W = G.u_n_waves; L = G.u_wave_len; n_samples = G.u_n_samples; wbase = c * W; }
+    else { const ChunkDesc d = G.chunks[c]; W = d.n_waves; L = d.wave_len; n_samples = d.n_samples; wbase = d.wave_base; }
     const uint64_t begin = chunk_word_off[c], end = chunk_word_off[c + 1];
     if (end > in_words || begin + 2 > end || end - begin > 0x7fffffffull) return;  // k_bw_scan flags the chunk
     const uint32_t len_w = (uint32_t)(end - begin);
@@ -1590,7 +1597,7 @@ __global__ __launch_bounds__(64) void k_bw_blocks(Geom G, const uint32_t *__rest
         return;
     }
     // EMIT: chase again from the accepted entry, writing the table
-    const uint64_t base = c * W + info[unit].base;
+    const uint64_t base = wbase + info[unit].base;
     uint32_t rel = entry - b0, w = 0;
     while (rel < blk_len) {
         uint32_t hops = 0;
@@ -1609,7 +1616,7 @@ __global__ __launch_bounds__(64) void k_bw_blocks(Geom G, const uint32_t *__rest
             wave_words[base + w0 + i] = h.y;
             // the chunk's last waveform may be shorter than the rest: its header has a tighter bound
             if (info[unit].base + w0 + i + 1u == W) {
-                const uint32_t max_last = (uint32_t)(((uint64_t)(G.u_n_samples - (W - 1u) * L) * 25u + 31u) >> 5);
+                const uint32_t max_last = (uint32_t)(((uint64_t)(n_samples - (W - 1u) * L) * 25u + 31u) >> 5);
                 if (h.y > max_last) atomicOr(&st->err, kErrCorrupt);
             }
         }
@@ -1619,18 +1626,21 @@ __global__ __launch_bounds__(64) void k_bw_blocks(Geom G, const uint32_t *__rest
 
 // one wavefront per chunk: stitch the blocks, first-waveform index of every block, verdict
 __global__ __launch_bounds__(64) void k_bw_scan(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
-                                                const uint64_t *__restrict__ chunk_word_off, uint32_t blocks_max,
-                                                BwBlock *__restrict__ info, uint32_t *__restrict__ fail) {
+                                                const uint64_t *__restrict__ chunk_word_off, const uint32_t *__restrict__ list,
+                                                uint32_t blocks_max, BwBlock *__restrict__ info, uint32_t *__restrict__ fail) {
     const int lane = lane_id();
-    const uint64_t c = blockIdx.x;
-    const uint32_t W = G.u_n_waves, L = G.u_wave_len, N = G.u_n_samples;
+    const uint64_t slot = blockIdx.x;
+    const uint64_t c = list ? (uint64_t)list[slot] : slot;
+    uint32_t W, L, N;
+    if (G.uniform) { W = G.u_n_waves; L = G.u_wave_len; N = G.u_n_samples; }
+    else { const ChunkDesc d = G.chunks[c]; W = d.n_waves; L = d.wave_len; N = d.n_samples; }
     const uint64_t begin = chunk_word_off[c], end = chunk_word_off[c + 1];
     bool bad = end > in_words || begin + 2 > end || end - begin > 0x7fffffffull;
     if (!bad && in[begin] != N) bad = true;
     const uint32_t len_w = bad ? 0u : (uint32_t)(end - begin);
     const uint32_t n_blocks = (len_w + kWalkBlockWords - 1u) / kWalkBlockWords;
     if (n_blocks > blocks_max) bad = true;
-    BwBlock *my = info + c * blocks_max;
+    BwBlock *my = info + slot * blocks_max;
     uint32_t run = 0;
     for (uint32_t b0 = 0; b0 < n_blocks && !bad; b0 += 64) {
         const uint32_t b = b0 + (uint32_t)lane;
@@ -2536,11 +2546,23 @@ uint32_t bw_walk_blocks_max(const Geom &G) {
     return nb > 0xfffffu ? 0u : (uint32_t)nb;
 }
 
-// scratch of the parallel header walks (0: the batch takes neither)
+// scratch of the parallel header walks (0: the batch takes neither); layout in launch_decode()
 uint64_t par_walk_scratch_bytes(const Geom &G) {
-    if (const uint32_t nb = bw_walk_blocks_max(G)) return G.n_chunks * ((uint64_t)nb * sizeof(BwBlock) + sizeof(uint32_t));
-    if (!(G.uniform && G.n_chunks <= kPwMaxChunks && G.u_n_waves <= kPwMaxWaves && G.u_n_waves >= 64u && G.u_wave_len > kWalkShortLen)) return 0;
-    return G.n_chunks * (kPwCap * sizeof(uint2) + 2u * sizeof(uint32_t));
+    bool pw, bw;
+    uint64_t bw_units;
+    if (G.uniform) {
+        const uint32_t nb = bw_walk_blocks_max(G);
+        bw = nb != 0;
+        bw_units = G.n_chunks * nb;
+        pw = !bw && G.n_chunks <= kPwMaxChunks && G.u_n_waves <= kPwMaxWaves && G.u_n_waves >= 64u && G.u_wave_len > kWalkShortLen;
+    } else {
+        if (!G.rag_par) return 0;
+        pw = G.n_long != 0;
+        bw = G.n_short != 0;
+        bw_units = (uint64_t)G.n_short * G.rag_bw_blocks_max;
+    }
+    if (!pw && !bw) return 0;
+    return (pw ? G.n_chunks * kPwCap * sizeof(uint2) : 0) + (3u * G.n_chunks + 2u) * sizeof(uint32_t) + bw_units * sizeof(BwBlock);
 }
 
 bool long_batch(const Geom &G) {
@@ -2603,9 +2625,10 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
     // ... and of short waveforms: the block-parallel walk
     const uint32_t bw_blocks_max = bw_walk_blocks_max(G);
     const bool bw_walk = d_pw && bw_blocks_max && !tables_ready && !(G.dbg & 2048u);
+    const bool rag_par = d_pw && !G.uniform && G.rag_par && !tables_ready && !(G.dbg & 2048u);
     const bool sparse = !G.uniform && (uint64_t)G.n_chunks * G.max_groups > 8ull * ((G.total_waves + 63u) / 64u) + 4096ull;
     const bool fused = (impl == 5 || impl == 6 || impl == 8 || impl == 14 || impl == 15 || impl == 17) && (!needs_block || big_ring) &&
-                       !((G.dbg & 8u) && needs_block) && !sparse && !long_path && !par_walk && !bw_walk;  // the in-launch walk needs the arithmetic chunk mapping
+                       !((G.dbg & 8u) && needs_block) && !sparse && !long_path && !par_walk && !bw_walk && !rag_par;  // the in-launch walk needs the arithmetic chunk mapping
     if (fused) {
         // granules + ticket word, zeroed before every launch (a granule is its own ready flag)
         hipError_t e = hipMemsetAsync(d_granules, 0, (G.total_waves + 2) * sizeof(uint64_t), s);
@@ -2634,28 +2657,33 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
     } else {
         // chunks of short waveforms: stream the chunk through LDS; long waveforms: one dependent load per hop
         if (tables_ready) {
-        } else if (par_walk) {
-            // scratch: uint2 cand[n_chunks * kPwCap] | uint32 count[n_chunks] | uint32 fail[n_chunks]
+        } else if (par_walk || bw_walk || rag_par) {
+            // scratch: uint2 cand[n_chunks * kPwCap] | uint32 count[n_chunks] | pw_fail[n_chunks] | bw_fail[n_chunks] |
+            //          BwBlock info[n_bw * bw_blocks]   (cand .. pw_fail only where the chunk-wide walk is used)
+            const bool use_pw = par_walk || (rag_par && G.n_long), use_bw = bw_walk || (rag_par && G.n_short);
+            const uint32_t *pw_list = G.uniform ? nullptr : G.walk_long, *bw_list = G.uniform ? nullptr : G.walk_short;
+            const uint32_t n_pw = G.uniform ? (uint32_t)G.n_chunks : G.n_long, n_bw = G.uniform ? (uint32_t)G.n_chunks : G.n_short;
+            const uint32_t bwb = G.uniform ? bw_blocks_max : G.rag_bw_blocks_max;
             uint2 *cand = reinterpret_cast<uint2 *>(d_pw);
-            uint32_t *cnt = reinterpret_cast<uint32_t *>(cand + G.n_chunks * kPwCap), *d_pw_fail = cnt + G.n_chunks;
-            hipError_t e = hipMemsetAsync(cnt, 0, 2u * G.n_chunks * sizeof(uint32_t), s);
+            uint32_t *cnt = reinterpret_cast<uint32_t *>(cand + (use_pw ? G.n_chunks * kPwCap : 0));
+            uint32_t *pw_fail = cnt + G.n_chunks, *bw_fail = pw_fail + G.n_chunks;
+            BwBlock *info = reinterpret_cast<BwBlock *>(bw_fail + G.n_chunks + (G.n_chunks & 1u));
+            hipError_t e = hipMemsetAsync(cnt, 0, 3u * G.n_chunks * sizeof(uint32_t), s);
             if (e != hipSuccess) return e;
-            k_pw_scan<<<(unsigned)(G.n_chunks * kPwParts), 256, 0, s>>>(G, d_in, in_words, d_chunk_word_off, cand, cnt);
-            k_walk_parallel<<<(unsigned)G.n_chunks, kPwThreads, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words,
-                                                                        d_pw_fail, cand, cnt);
-            k_walk_scalar_only<<<blocks_for(G.n_chunks, kWalkChains), 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off,
-                                                                                  d_wave_words, d_status, d_pw_fail);
-            if (impl == 5) impl = 1;
-            if (impl == 8 || impl == 14 || impl == 15 || impl == 17) impl = 7;
-        } else if (bw_walk) {
-            // scratch: BwBlock info[n_chunks * blocks_max] | uint32 fail[n_chunks]
-            BwBlock *info = reinterpret_cast<BwBlock *>(d_pw);
-            const uint64_t units = G.n_chunks * bw_blocks_max;
-            uint32_t *bw_fail = reinterpret_cast<uint32_t *>(info + units);
-            k_bw_blocks<false><<<(unsigned)units, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, bw_blocks_max, info, nullptr, nullptr, nullptr, d_status);
-            k_bw_scan<<<(unsigned)G.n_chunks, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, bw_blocks_max, info, bw_fail);
-            k_bw_blocks<true><<<(unsigned)units, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, bw_blocks_max, info, bw_fail, d_wave_off, d_wave_words, d_status);
-            k_walk_block_only<<<(unsigned)G.n_chunks, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_status, bw_fail);
+            if (use_pw) {
+                k_pw_scan<<<(unsigned)(n_pw * kPwParts), 256, 0, s>>>(G, d_in, in_words, d_chunk_word_off, pw_list, cand, cnt);
+                k_walk_parallel<<<n_pw, kPwThreads, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words,
+                                                            pw_fail, pw_list, cand, cnt);
+                k_walk_scalar_only<<<blocks_for(G.n_chunks, kWalkChains), 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off,
+                                                                                      d_wave_words, d_status, pw_fail);
+            }
+            if (use_bw) {
+                const uint64_t units = (uint64_t)n_bw * bwb;
+                k_bw_blocks<false><<<(unsigned)units, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, bw_list, n_bw, bwb, info, nullptr, nullptr, nullptr, d_status);
+                k_bw_scan<<<n_bw, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, bw_list, bwb, info, bw_fail);
+                k_bw_blocks<true><<<(unsigned)units, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, bw_list, n_bw, bwb, info, bw_fail, d_wave_off, d_wave_words, d_status);
+                k_walk_block_only<<<(unsigned)G.n_chunks, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_status, bw_fail);
+            }
             if (impl == 5) impl = 1;
             if (impl == 8 || impl == 14 || impl == 15 || impl == 17) impl = 7;
         } else if (G.uniform) {

@@ -594,7 +594,10 @@ __global__ __launch_bounds__(64 * kEncWaves) void k_encode_fused(Geom G, const i
     WaveRef r = locate(G, live ? g : 0);
     if (!live) { r.len = 0; r.idx = 1; }  // an idle wave of the last workgroup: nothing to encode, nothing to add
     const int16_t *x = in + r.sample_off;
-    const bool vec_ok = ((uintptr_t)x & 15u) == 0;
+    // 16-byte loads at any int16 alignment (unaligned access is on for HSA queues): a WaveformLength like 3500 puts
+    // every other waveform 8 bytes off a 16-byte boundary, an odd one 2 bytes off a dword, and the per-sample
+    // fallback is 2x slower (dbg 4096 keeps the old 16-byte rule)
+    const bool vec_ok = (G.dbg & 4096u) ? ((uintptr_t)x & 15u) == 0 : true;
     const uint32_t k = G.k;
     wave_sync();
 
@@ -868,7 +871,7 @@ __device__ __forceinline__ SegRef locate_seg(const Geom &G, uint64_t u, uint32_t
 template <typename F>
 __device__ __forceinline__ void for_segment_tiles(const int16_t *__restrict__ xw, const SegRef &q, uint32_t k, int lane, F &&tile) {
     const int16_t *x = xw + q.start;
-    const bool vec_ok = ((uintptr_t)x & 15u) == 0;
+    const bool vec_ok = true;  // any int16 alignment (see k_encode_fused)
     // dword whose high half is the sample before the segment (x[-1] := 0 at the start of the waveform, :53-54)
     // (a unit past the end of a shorter last waveform has count == 0: nothing of it may be touched)
     uint32_t carry = (q.start && q.count) ? ((uint32_t)(uint16_t)xw[q.start - 1u] << 16) : 0u;
@@ -2540,7 +2543,10 @@ uint32_t bw_walk_blocks_max(const Geom &G) {
     // the two block passes cost ~15 us per chunk, the serial chase ~0.13 us per waveform of a chunk (all chunks at
     // once) and large batches hide most of it: measured crossovers 150 chunks at L = 512, 80 at L = 2048
     const uint64_t limit = G.u_n_waves / 100u < 150u ? G.u_n_waves / 100u : 150u;
-    if (!(G.uniform && G.n_chunks <= limit && G.u_wave_len <= kWalkShortLen && G.u_wave_len >= 16u)) return 0;
+    // every 4096-word block must hold a header: n_i <= 25 L / 32 < 4096, i.e. L <= 5000; chunks of longer
+    // waveforms within the chunk-wide walk's capacity take that one
+    const bool chunk_wide = G.u_wave_len > kWalkShortLen && G.u_n_waves <= kPwMaxWaves && G.u_n_waves >= 64u;
+    if (!(G.uniform && G.n_chunks <= limit && G.u_wave_len <= 5000u && G.u_wave_len >= 16u && !chunk_wide)) return 0;
     const uint64_t max_words = 1u + G.u_n_waves + (((uint64_t)G.u_n_samples * 25u + 31u) >> 5) + G.u_n_waves;
     const uint64_t nb = (max_words + kWalkBlockWords - 1u) / kWalkBlockWords;
     return nb > 0xfffffu ? 0u : (uint32_t)nb;

@@ -2542,7 +2542,9 @@ uint64_t long_decode_scratch_bytes(const Geom &G) {
 uint32_t bw_walk_blocks_max(const Geom &G) {
     // the two block passes cost ~15 us per chunk, the serial chase ~0.13 us per waveform of a chunk (all chunks at
     // once) and large batches hide most of it: measured crossovers 150 chunks at L = 512, 80 at L = 2048
-    const uint64_t limit = G.u_n_waves / 100u < 150u ? G.u_n_waves / 100u : 150u;
+    // (above WaveformLength 2048 the alternative is the scalar chain at 0.85 us per hop, 6.5x the LDS chase: W / 18)
+    const uint64_t per = G.u_wave_len <= kWalkShortLen ? 100u : 18u, cap = G.u_wave_len <= kWalkShortLen ? 150u : kPwMaxChunks;
+    const uint64_t limit = G.u_n_waves / per < cap ? G.u_n_waves / per : cap;
     // every 4096-word block must hold a header: n_i <= 25 L / 32 < 4096, i.e. L <= 5000; chunks of longer
     // waveforms within the chunk-wide walk's capacity take that one
     const bool chunk_wide = G.u_wave_len > kWalkShortLen && G.u_n_waves <= kPwMaxWaves && G.u_n_waves >= 64u;

@@ -475,3 +475,38 @@ def test_segment_encoder_units_past_a_short_last_waveform(ctx, O):
         w, off = plan.encode(dev(ctx, x)).to_numpy()
         assert np.array_equal(off, ref_off) and np.array_equal(w, ref_w)
         assert np.array_equal(plan.decode(plan.encode(dev(ctx, x))).cpu().numpy(), x)
+
+
+def test_corrupt_headers_through_the_parallel_walks(ctx, O):
+    """The parallel header walks (chunk-wide candidates for long waveforms, block-parallel for short ones) must
+    reach the same verdict as the serial walkers: a broken chain is DRX_ERR_CORRUPT, never a wrong table."""
+    import deltarice_amd as dr
+    rng = np.random.default_rng(5)
+    for L, W, n_chunks in ((7000, 200, 3), (512, 3000, 2), (3000, 900, 2)):
+        x = rng.normal(0, 10, n_chunks * W * L).astype(np.int16)
+        opts = (8, L)
+        ref_w, ref_off = O.encode_batch(x, W * L, opts)
+        plan = ctx.plan_uniform(n_chunks, W * L, opts)
+        good = dr.EncodedBatch(dev(ctx, ref_w.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), ref_w.size)
+        for flags in (0, 2048):  # parallel walk / the serial walkers
+            ctx.set_option("debug_flags", flags)
+            assert np.array_equal(plan.decode(good).cpu().numpy(), x)
+        ctx.set_option("debug_flags", 0)
+        # header positions of chunk 1
+        pos = [int(ref_off[1]) + 1]
+        for _ in range(W - 1):
+            pos.append(pos[-1] + int(ref_w[pos[-1]]) + 1)
+        for which, delta in ((0, 1), (W // 2, 1), (W // 2, -1), (W - 1, 1), (W // 3, 1 << 20), (5, 0x7FFFFFFF)):
+            bad = ref_w.copy()
+            bad[pos[which]] = (int(bad[pos[which]]) + delta) & 0xFFFFFFFF
+            enc = dr.EncodedBatch(dev(ctx, bad.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), bad.size)
+            for flags in (0, 2048):
+                ctx.set_option("debug_flags", flags)
+                with pytest.raises(dr.DeltaRiceError) as e:
+                    plan.decode(enc)
+                assert e.value.status == 4, (L, which, delta, flags)
+            ctx.set_option("debug_flags", 0)
+        bad = ref_w.copy()
+        bad[int(ref_off[1])] += 1  # the chunk's sample count
+        with pytest.raises(dr.DeltaRiceError):
+            plan.decode(dr.EncodedBatch(dev(ctx, bad.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), bad.size))

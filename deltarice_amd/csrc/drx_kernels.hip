@@ -894,15 +894,19 @@ __device__ __forceinline__ void for_segment_tiles(const int16_t *__restrict__ xw
 }
 
 __global__ __launch_bounds__(256) void k_seg_sizes(Geom G, const int16_t *__restrict__ in, uint32_t segs_per_wave,
-                                                   uint64_t n_units, uint32_t *__restrict__ seg_bits) {
+                                                   uint64_t n_units, uint32_t upw, uint32_t *__restrict__ seg_bits) {
     const int lane = lane_id();
-    const uint64_t u = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (u >= n_units) return;
-    const SegRef q = locate_seg(G, u, segs_per_wave);
-    uint32_t bits = 0;  // <= 8192 * 25
-    for_segment_tiles(in + q.r.sample_off, q, G.k, lane,
-                      [&](const PackedCodes &, uint32_t, uint32_t, uint32_t tile_bits, bool) { bits += tile_bits; });
-    if (lane == 0) seg_bits[u] = bits;
+    // upw consecutive units per wavefront: with one-tile waveforms the launch of a wavefront costs as much as its work
+    const uint64_t u0 = ((uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * upw;
+    for (uint32_t rep = 0; rep < upw; ++rep) {
+        const uint64_t u = u0 + rep;
+        if (u >= n_units) return;
+        const SegRef q = locate_seg(G, u, segs_per_wave);
+        uint32_t bits = 0;  // <= 8192 * 25
+        for_segment_tiles(in + q.r.sample_off, q, G.k, lane,
+                          [&](const PackedCodes &, uint32_t, uint32_t, uint32_t tile_bits, bool) { bits += tile_bits; });
+        if (lane == 0) seg_bits[u] = bits;
+    }
 }
 
 // one wavefront per waveform: exclusive prefix of its segments' bits (a waveform has < 2^31 * 25 / 2^32 ... bits
@@ -948,61 +952,66 @@ __global__ __launch_bounds__(256) void k_seg_pack(Geom G, const int16_t *__restr
                                                   uint64_t n_units, const uint64_t *__restrict__ seg_pos,
                                                   const uint32_t *__restrict__ wave_words, const uint32_t *__restrict__ wave_rel,
                                                   const uint64_t *__restrict__ chunk_word_off, uint32_t *__restrict__ out,
-                                                  uint64_t out_cap) {
+                                                  uint64_t out_cap, uint32_t upw) {
     // per wave: 4 pad words (place_words ORs zeros below a lane's first word), the stage, slack
     __shared__ __attribute__((aligned(16))) uint32_t stage_all[4][4 + kStageWords + 12];
     const int lane = lane_id();
     uint32_t *row = stage_all[threadIdx.x >> 6];
     uint32_t *stage = row + 4;
-    const uint64_t u = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (u >= n_units) return;
-    const SegRef q = locate_seg(G, u, segs_per_wave);
-    if (q.count == 0) return;
-    for (int i = lane; i < 4 + (int)kStageWords + 12; i += 64) row[i] = 0;
-    const uint64_t pos = chunk_word_off[q.r.chunk] + wave_rel[q.g];  // the waveform's header word
-    const uint32_t n = wave_words[q.g];
-    if (pos + 1u + n > out_cap) return;  // k_chunk_offsets has raised kErrCapacity
-    if (q.s == 0 && lane == 0) {
-        out[pos] = n;                                    // :379
-        if (q.r.idx == 0) out[pos - 1] = q.r.n_samples;  // chunk header, :415
-    }
-    const uint64_t B = seg_pos[u];
-    uint32_t *__restrict__ outp = out + pos + 1 + (B >> 5);  // the word that holds the segment's first bit
-    const uint32_t stage_bits = lds_addr(stage) * 8u;
-    uint32_t P = (uint32_t)(B & 31u);  // bits in the stage, counted from the start of outp[wdone]
-    uint32_t wdone = 0;                // words of outp already written
-    bool shared_first = (B & 31u) != 0;  // outp[0] also holds the end of the previous segment
-    wave_sync();
-    for_segment_tiles(in + q.r.sample_off, q, G.k, lane,
-                      [&](const PackedCodes &c, uint32_t lane_bits, uint32_t incl, uint32_t tile_bits, bool full) {
-        if (full && !__any(lane_bits > 128u)) {
-            uint32_t cw[4];
-            concat_codes(c, cw);
-            place_words(cw, stage_bits + P + incl);
-        } else {
-            emit_tile<false>(c, stage_bits + P + incl - lane_bits);
+    const uint64_t u0 = ((uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * upw;
+    for (uint32_t rep = 0; rep < upw; ++rep) {
+        const uint64_t u = u0 + rep;
+        if (u >= n_units) return;
+        const SegRef q = locate_seg(G, u, segs_per_wave);
+        if (q.count == 0) continue;
+        for (int i = lane; i < 4 + (int)kStageWords + 12; i += 64) row[i] = 0;
+        const uint64_t pos = chunk_word_off[q.r.chunk] + wave_rel[q.g];  // the waveform's header word
+        const uint32_t n = wave_words[q.g];
+        if (pos + 1u + n > out_cap) continue;  // k_chunk_offsets has raised kErrCapacity
+        if (q.s == 0 && lane == 0) {
+            out[pos] = n;                                    // :379
+            if (q.r.idx == 0) out[pos - 1] = q.r.n_samples;  // chunk header, :415
         }
-        P += tile_bits;
+        const uint64_t B = seg_pos[u];
+        uint32_t *__restrict__ outp = out + pos + 1 + (B >> 5);  // the word that holds the segment's first bit
+        const uint32_t stage_bits = lds_addr(stage) * 8u;
+        uint32_t P = (uint32_t)(B & 31u);  // bits in the stage, counted from the start of outp[wdone]
+        uint32_t wdone = 0;                // words of outp already written
+        bool shared_first = (B & 31u) != 0;  // outp[0] also holds the end of the previous segment
         wave_sync();
-        const uint32_t nfull = P >> 5;
-        for (uint32_t i = lane; i < nfull; i += 64) {
-            const uint32_t v = stage[i];
-            stage[i] = 0;
-            if (i == 0 && shared_first) atomicOr(outp + wdone, v); else outp[wdone + i] = v;
+        for_segment_tiles(in + q.r.sample_off, q, G.k, lane,
+                          [&](const PackedCodes &c, uint32_t lane_bits, uint32_t incl, uint32_t tile_bits, bool full) {
+            if (full && !__any(lane_bits > 128u)) {
+                uint32_t cw[4];
+                concat_codes(c, cw);
+                place_words(cw, stage_bits + P + incl);
+            } else {
+                emit_tile<false>(c, stage_bits + P + incl - lane_bits);
+            }
+            P += tile_bits;
+            wave_sync();
+            const uint32_t nfull = P >> 5;
+            for (uint32_t i = lane; i < nfull; i += 64) {
+                const uint32_t v = stage[i];
+                stage[i] = 0;
+                if (i == 0 && shared_first) atomicOr(outp + wdone, v); else outp[wdone + i] = v;
+            }
+            wave_sync();
+            if (nfull) {
+                if (lane == 0) { const uint32_t cwd = stage[nfull]; stage[nfull] = 0; stage[0] = cwd; }
+                shared_first = false;
+                wdone += nfull;
+                P &= 31u;
+            }
+            wave_sync();
+        });
+        if (P && lane == 0) {
+            // the last, partly filled word: the next segment continues in it, unless the waveform ends here
+            // (then it is left aligned and zero padded, :237-241)
+            if (q.last && !shared_first) outp[wdone] = stage[0]; else atomicOr(outp + wdone, stage[0]);
         }
+
         wave_sync();
-        if (nfull) {
-            if (lane == 0) { const uint32_t cwd = stage[nfull]; stage[nfull] = 0; stage[0] = cwd; }
-            shared_first = false;
-            wdone += nfull;
-            P &= 31u;
-        }
-        wave_sync();
-    });
-    if (P && lane == 0) {
-        // the last, partly filled word: the next segment continues in it, unless the waveform ends here
-        // (then it is left aligned and zero padded, :237-241)
-        if (q.last && !shared_first) outp[wdone] = stage[0]; else atomicOr(outp + wdone, stage[0]);
     }
 }
 
@@ -2590,15 +2599,16 @@ hipError_t launch_encode_long(const Geom &G, const int16_t *d_in, uint32_t *d_ou
     const uint32_t S = G.uniform ? uniform_segments(G) : 0u;
     const uint64_t units = long_batch_units(G);
     mark(ev, 0, s);
-    k_seg_sizes<<<blocks_for(units, 4), 256, 0, s>>>(G, d_in, S, units, d_seg_bits);
+    const uint32_t upw = (G.uniform && S == 1u && G.u_wave_len <= 1024u) ? 8u : 1u;  // short waveforms: eight per wavefront
+    k_seg_sizes<<<blocks_for(units, 4 * upw), 256, 0, s>>>(G, d_in, S, units, upw, d_seg_bits);
     mark(ev, 1, s);
     k_seg_scan<<<(unsigned)G.total_waves, 64, 0, s>>>(G, S, d_seg_bits, d_seg_pos, d_wave_words);
     k_chunk_scan<<<(unsigned)G.n_chunks, 256, 0, s>>>(G, d_wave_words, d_wave_rel, d_chunk_words);
     k_chunk_offsets<<<1, 1024, 0, s>>>(G.n_chunks, d_chunk_words, d_chunk_word_off, out_cap, d_status);
     k_seg_zero<<<blocks_for(units, 256), 256, 0, s>>>(G, S, units, d_seg_pos, d_wave_rel, d_chunk_word_off, d_out, out_cap);
     mark(ev, 2, s);
-    k_seg_pack<<<blocks_for(units, 4), 256, 0, s>>>(G, d_in, S, units, d_seg_pos, d_wave_words, d_wave_rel, d_chunk_word_off,
-                                                    d_out, out_cap);
+    k_seg_pack<<<blocks_for(units, 4 * upw), 256, 0, s>>>(G, d_in, S, units, d_seg_pos, d_wave_words, d_wave_rel, d_chunk_word_off,
+                                                          d_out, out_cap, upw);
     mark(ev, 3, s);
     return hipGetLastError();
 }

@@ -40,6 +40,7 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
+    scale = int(os.environ.get("DRX_FUZZ_SCALE", 1))  # multiplies the chunk-size caps (bigger, fewer cases)
     ctx = dr.Context(0)
     t0 = time.time()
     lo, hi = 0, cases
@@ -66,10 +67,10 @@ def main():
             taps = [int(rng.choice([1, -1])) if rng.random() < 0.8 else int(rng.integers(2, 5))] + [int(v) for v in rng.integers(-3, 4, nt - 1)]
         if ragged:
             Ls = [int(rng.choice(Lc)) for _ in range(n_chunks)]
-            Ns = [int(min(400000, max(1, L * int(rng.integers(1, 40)) + int(rng.integers(0, L))))) for L in Ls]
+            Ns = [int(min(400000 * scale, max(1, L * int(rng.integers(1, 40 * scale)) + int(rng.integers(0, L))))) for L in Ls]
         else:
             L = int(rng.choice(Lc))
-            N = int(min(600000, max(1, L * int(rng.integers(1, 60)) + (int(rng.integers(0, L)) if rng.random() < 0.5 else 0))))
+            N = int(min(600000 * scale, max(1, L * int(rng.integers(1, 60 * scale)) + (int(rng.integers(0, L)) if rng.random() < 0.5 else 0))))
             Ls, Ns = [L] * n_chunks, [N] * n_chunks
         if k == 0:
             kind = "zeros" if kind == "uniform" else kind  # M = 1 is defined only while z < 32768

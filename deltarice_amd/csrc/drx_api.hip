@@ -318,7 +318,7 @@ drx_status drx_plan_create(drx_ctx *ctx, uint64_t n_chunks, const uint32_t *chun
         bool seg = false;
         std::vector<uint64_t> ub(n_chunks + 1, 0);
         for (uint64_t c = 0; c < n_chunks; ++c) {
-            seg = seg || desc[c].wave_len <= kWalkShortLenHost || desc[c].wave_len >= 16384u;
+            seg = seg || desc[c].wave_len <= kSegShortLenHost || desc[c].wave_len >= kSegLongLenHost;
             ub[c + 1] = ub[c] + (uint64_t)desc[c].n_waves * ((desc[c].wave_len + 8191u) / 8192u);
         }
         if (seg) {

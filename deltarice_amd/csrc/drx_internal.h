@@ -96,6 +96,8 @@ uint32_t bw_walk_blocks_max(const Geom &G);
 // scratch of the workgroup-per-block decoder of a handful of long waveforms (0: that path is not taken)
 uint64_t long_decode_scratch_bytes(const Geom &G);
 constexpr uint32_t kWalkShortLenHost = 2048;  // keep equal to kWalkShortLen in drx_kernels.hip
+// WaveformLengths the segment encoder takes in any batch: up to kSegShortLenHost, and from kSegLongLenHost
+constexpr uint32_t kSegShortLenHost = 3072, kSegLongLenHost = 10240;
 // limits of the parallel header walks (see k_walk_parallel / k_bw_blocks)
 constexpr uint32_t kPwMaxWaves = 3584;   // waveforms per chunk the chunk-wide walk takes (leaves room for impostors)
 constexpr uint64_t kPwMaxChunks = 224;   // more chunks hide the serial walk behind the decoding, and reading the stream

@@ -2545,8 +2545,8 @@ uint64_t long_decode_scratch_bytes(const Geom &G) {
 
 // Batches the segment encoder takes: few long waveforms, and SHORT waveforms (one segment each), where the
 // single-pass encoder pays a workgroup barrier, a look-back and an 8 KB LDS clear per 512-2048 samples
-// (200 chunks of 14 M samples: L = 512 0.57 -> 0.95 TB/s, 1024 0.97 -> 1.33, 2048 1.51 -> 1.68; 7000 is better off
-// with the single pass)
+// (200 chunks of 14 M samples: L = 512 0.57 -> 0.95 TB/s, 1024 0.97 -> 1.33, 2048 1.51 -> 1.68), and waveforms
+// long enough to outgrow the single pass's LDS buffer; in between the single pass is better
 // block-parallel walk of short waveforms: blocks per chunk at 25 bits per sample (0: the batch does not take it)
 uint32_t bw_walk_blocks_max(const Geom &G) {
     // the two block passes cost ~15 us per chunk, the serial chase ~0.13 us per waveform of a chunk (all chunks at
@@ -2585,7 +2585,11 @@ uint64_t par_walk_scratch_bytes(const Geom &G) {
 bool long_batch(const Geom &G) {
     if (G.n_taps) return false;
     if (!G.uniform) return G.seg_unit_base != nullptr;  // decided when the plan was made (some chunk is short or long)
-    return long_waveform_batch(G.total_waves, G.u_wave_len) || G.u_wave_len <= kWalkShortLen;
+    // measured at 100 chunks of 14 M samples (single pass / segments, TB/s): L = 2049 0.95 / 1.06, 3000 1.57 / 1.64,
+    // 4096 1.93 / 1.85, 7000 2.16 / 1.87, 12000 1.33 / 1.63 (the single pass outgrows its 8 KB LDS buffer at
+    // ~6.5 bits per sample and encodes such waveforms twice)
+    return long_waveform_batch(G.total_waves, G.u_wave_len) || G.u_wave_len <= kSegShortLenHost || G.u_wave_len >= kSegLongLenHost ||
+           (G.dbg & 8192u);
 }
 static uint32_t uniform_segments(const Geom &G) { return (G.u_wave_len + kSegSamples - 1u) / kSegSamples; }
 uint64_t long_batch_units(const Geom &G) { return G.uniform ? G.total_waves * uniform_segments(G) : G.seg_units; }

@@ -1834,10 +1834,16 @@ __global__ __launch_bounds__(kLongThreads) void k_decode_long(Geom G, const uint
         uint32_t Q = 0u - start;  // minus the bit position
         const uint32_t lim = avail_bits < kLongSegBits ? avail_bits : kLongSegBits;
         const int32_t nlim = enable ? -(int32_t)lim : 1;  // a code is taken while -Q < lim, i.e. Q > -lim
-        // EMIT: two samples per store where they share an aligned dword (2-byte stores run into the L2's request
-        // rate: 350 M of them in 2 ms); held: the sample waiting for its partner
-        const uint32_t par0 = (uint32_t)(((uintptr_t)y >> 1) & 1u);  // parity of sample 0's address in int16 units
-        uint32_t held = 0, held_i = 0;
+        // EMIT: four samples per store where they fill an aligned 8 bytes (2-byte stores run into the L2's request
+        // rate: 350 M of them in 2 ms; ablation: the stores were a third of the kernel).  q4: the last four samples,
+        // newest on top; nh: how many of them have not been stored yet; last_i: index of the newest one.
+        // (MULTI, one block per workgroup: quads, -12 %; a workgroup that walks its waveform block by block did better
+        // with pairs -- 65 536-sample waveforms 1.9 ms against 2.1 ms -- so it keeps them: QUADS below)
+        constexpr bool QUADS = MULTI;
+        const uint32_t par4 = (uint32_t)(((uintptr_t)y >> 1) & 3u);  // sample 0's slot in its aligned quad (pairs: & 1)
+        uint64_t q4 = 0;
+        uint32_t nh = 0, last_i = 0;   // QUADS
+        uint32_t held = 0, held_i = 0;  // pairs: the sample waiting for its partner
         bool holding = false;
         // LDS byte address of this thread's row of word 0
         const uint32_t row0 = lds_addr(col) + ((kLongRows - 2u) * NT + tid) * 4u;
@@ -1856,17 +1862,31 @@ __global__ __launch_bounds__(kLongThreads) void k_decode_long(Geom G, const uint
                 const uint32_t d = (z >> 1) ^ (0u - (z & 1u));
                 const uint32_t s2 = sacc + d;
                 if (EMIT) {
-                    if (act && idx + c < len) {
+                    if (act && idx + c < len && !(G.dbg & 16384u)) {  // (16384: ablation, no stores)
                         const uint32_t i = idx + c;
-                        if (((i + par0) & 1u) == 0u) {  // low half of an aligned dword: wait for the next sample
-                            held = s2 & 0xffffu;
-                            held_i = i;
-                            holding = true;
-                        } else if (holding) {
-                            *reinterpret_cast<uint32_t *>(y + i - 1u) = held | (s2 << 16);
-                            holding = false;
+                        if constexpr (QUADS) {
+                            q4 = (q4 >> 16) | ((uint64_t)(s2 & 0xffffu) << 48);
+                            ++nh;
+                            last_i = i;
+                            if (((i + par4) & 3u) == 3u) {  // the quad is complete
+                                if (nh == 4u) {
+                                    *reinterpret_cast<uint64_t *>(y + i - 3u) = q4;
+                                } else {  // the lane started inside this quad
+                                    for (uint32_t j = 0; j < nh; ++j) y[i - j] = (int16_t)(uint16_t)(q4 >> (48u - 16u * j));
+                                }
+                                nh = 0;
+                            }
                         } else {
-                            y[i] = (int16_t)(uint16_t)s2;  // the lane's first sample sits in a high half
+                            if (((i + par4) & 1u) == 0u) {  // low half of an aligned dword: wait for the next sample
+                                held = s2 & 0xffffu;
+                                held_i = i;
+                                holding = true;
+                            } else if (holding) {
+                                *reinterpret_cast<uint32_t *>(y + i - 1u) = held | (s2 << 16);
+                                holding = false;
+                            } else {
+                                y[i] = (int16_t)(uint16_t)s2;  // the lane's first sample sits in a high half
+                            }
                         }
                     }
                 }
@@ -1875,7 +1895,10 @@ __global__ __launch_bounds__(kLongThreads) void k_decode_long(Geom G, const uint
                 c += act ? 1u : 0u;
             }
         }
-        if (EMIT && holding) y[held_i] = (int16_t)(uint16_t)held;  // the lane's last sample had no partner
+        if (EMIT) {  // the lane's last samples did not fill a quad / the last sample had no partner
+            if (QUADS) { for (uint32_t j = 0; j < nh; ++j) y[last_i - j] = (int16_t)(uint16_t)(q4 >> (48u - 16u * j)); }
+            else if (holding) y[held_i] = (int16_t)(uint16_t)held;
+        }
         const uint32_t pos = 0u - Q;
         end = pos;
         cnt = c;

@@ -11,6 +11,11 @@ HDF5 chunks of 2000 x 7000 (the reference's Nab chunk shape, docs/Performance.md
 
 N > 1: weak scaling -- every rank encodes/decodes its own 1M-waveform shard on its own
 GPU; the only collective is the all-gather of encoded sizes (deltarice_amd/dist.py).
+Without a launcher (WORLD_SIZE unset) `--gpus N` starts the N ranks itself: the parent
+touches no GPU, checks that N devices exist, spawns one child per GPU (RANK/LOCAL_RANK/
+WORLD_SIZE/MASTER_* in the environment, rendezvous on 127.0.0.1) and exits with their code.
+Every rank verifies the group's world size against --gpus; the JSON line carries
+`ranks_seen`, each rank's device and each rank's encoded size.
 
 Rank 0 prints ONE JSON line.  `roofline` is for the decode kernel (north_star's
 target): algorithmic bytes = 2*(1+ratio) per sample over the kernel's mean duration
@@ -21,9 +26,13 @@ that library is absent -- on a bounded sample of the same workload on the host c
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -78,56 +87,105 @@ def synth(device, n_waves, L, kind, seed):
 
 
 def cpu_baseline(x_host_chunks, opts, budget_s):
-    """Times the CPU filter on whole chunks until the budget is spent; GB/s of raw bytes
-    over encode+decode time."""
-    from oracle import oracle as O
-    use_ref = O.have_ref("omp")
-    t_enc = t_dec = 0.0
-    done = 0
-    raw = 0
-    t_start = time.perf_counter()
-    for xc in x_host_chunks:
-        if use_ref:
-            t0 = time.perf_counter(); enc = O.ref_filter(xc, opts, False); t1 = time.perf_counter()
-            t2 = time.perf_counter(); dec = O.ref_filter(enc, opts, True); t3 = time.perf_counter()
-            ok = dec == xc.tobytes()
-        else:
-            t0 = time.perf_counter(); w = O.encode_chunk(xc, opts); t1 = time.perf_counter()
-            t2 = time.perf_counter(); y = O.decode_chunk(w, opts, fast=True); t3 = time.perf_counter()
-            ok = np.array_equal(y, xc.reshape(-1))
-        assert ok, "cpu baseline round trip failed"
-        t_enc += t1 - t0
-        t_dec += t3 - t2
-        raw += xc.nbytes
-        done += 1
-        if time.perf_counter() - t_start > budget_s:
-            break
-    cores = int(os.environ.get("OMP_NUM_THREADS", 0)) or O.num_threads()
+    """The CPU filter on a bounded sample of the workload, in child processes (oracle/cpu_time.py) so that
+    OMP_NUM_THREADS takes effect: all host threads, then one thread (the reference publishes both,
+    docs/Performance.md:24-25).  Only the filter call is timed (buffers are filled / read outside the timer)."""
+    n_threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    arr = np.stack([np.ascontiguousarray(c).reshape(-1) for c in x_host_chunks])
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    fd, path = tempfile.mkstemp(suffix=".npy", dir=shm)
+    os.close(fd)
+    try:
+        np.save(path, arr)
+        legs = {}
+        for name, th, share in (("all", n_threads, 0.5), ("one", 1, 0.5)):
+            env = dict(os.environ, OMP_NUM_THREADS=str(th), OMP_PROC_BIND="false")
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_time.py"), path, str(opts[0]), str(opts[1]),
+                                str(budget_s * share)], env=env, capture_output=True, text=True, timeout=600)
+            if r.returncode != 0:
+                raise RuntimeError("cpu baseline leg failed: " + r.stderr[-2000:])
+            legs[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    finally:
+        os.unlink(path)
+    a, o = legs["all"], legs["one"]
+    what = ("H5Z_filter_deltarice of src/deltaRice.c (oracle/_ref, OpenMP build)" if a["kind"] == "reference"
+            else "oracle/deltarice_oracle.c (OpenMP)")
     return {
-        "value": raw / (t_enc + t_dec) / 1e9, "unit": "GB/s", "cores": cores,
-        "kind": "reference" if use_ref else "port",
-        "encode_GBps": raw / t_enc / 1e9, "decode_GBps": raw / t_dec / 1e9,
-        "sample": f"{done} chunks of the bench workload ({raw / 1e6:.0f} MB raw), "
-                  f"{'H5Z_filter_deltarice of src/deltaRice.c (OpenMP build, ctypes copies included)' if use_ref else 'oracle/deltarice_oracle.c (OpenMP)'}",
+        "value": a["value"], "unit": "GB/s", "cores": a["threads"], "kind": a["kind"], "cpu": a["cpu"],
+        "encode_GBps": a["encode_GBps"], "decode_GBps": a["decode_GBps"],
+        "one_thread": {"value": o["value"], "encode_GBps": o["encode_GBps"], "decode_GBps": o["decode_GBps"],
+                       "cores": o["threads"], "chunks": o["chunks"]},
+        "sample": f"{a['chunks']} chunks ({a['raw_bytes'] / 1e6:.0f} MB raw) of the bench workload with {a['threads']} threads, "
+                  f"{o['chunks']} chunks with 1 thread; {what}; only the filter call is timed",
     }
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(a):
+    """`--gpus N` without a launcher: start the N ranks here.  Nothing in this process has initialised the GPU
+    (torch.cuda.device_count() does not), so the children are ordinary fresh processes."""
+    have = torch.cuda.device_count()
+    need = 1 if a.backend != "nccl" else a.gpus
+    if have < need:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} needs {need} visible GPUs, this host shows {have}")
+    port = free_port()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:  # a rank died: the others would wait in the rendezvous for ever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    raise SystemExit(rc)
 
 
 def main():
     a = parse_args()
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)  # does not return
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.backend == "nccl":
+            if torch.cuda.device_count() <= local:
+                raise SystemExit(f"bench.py: rank {rank} wants GPU {local}, this host shows {torch.cuda.device_count()}")
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             local = 0  # rehearsal: every rank on the one visible GPU
             dist.init_process_group(a.backend)
+        if dist.get_world_size() != a.gpus:
+            raise SystemExit(f"bench.py: the process group has {dist.get_world_size()} ranks, --gpus says {a.gpus}")
     import deltarice_amd as dr
     from deltarice_amd import dist as drdist
 
@@ -202,22 +260,35 @@ def main():
     achieved = algo_bytes / (dec_kernel_ms * 1e-3) / 1e9
     pack_ms = float(np.mean(np.array(coll["enc"])[:, 2]))
 
-    traffic = traffic_enc = None
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tpath) and n_waves == 1_000_000 and L == 7000 and a.m == 8 and a.dist == "gauss":
-        # HBM bytes per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE x 2 + WRITE_SIZE,
-        # see profiles/make_traffic_json.py); PMC cannot be collected from inside the timed process
-        with open(tpath) as f:
+    # HBM bytes per launch: NOT measured by this run (PMC counters cannot be collected from inside the timed
+    # process) but read from the committed rocprofv3 --pmc passes of this same command and workload
+    # (FETCH_SIZE x 2 + WRITE_SIZE, profiles/make_traffic_json.py); `traffic_source` says so in the JSON line
+    traffic = traffic_enc = traffic_source = None
+    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    if tfiles and n_waves == 1_000_000 and L == 7000 and a.m == 8 and a.dist == "gauss":
+        with open(tfiles[-1]) as f:
             tk = json.load(f)["kernels"]
         traffic = tk.get("k_decode_lanes", {}).get("hbm_bytes")
         traffic_enc = tk.get("k_encode_fused", {}).get("hbm_bytes")
+        traffic_source = (f"profiles/{os.path.basename(tfiles[-1])}: rocprofv3 --pmc passes of this command on an earlier "
+                          "run, not collected by this run")
+
+    # every rank reports its device and encoded size: rank 0 prints what it SAW, not what it was told
+    rank_info = [[rank, local, total_words * 4]]
+    if world > 1:
+        t = torch.tensor(rank_info[0], dtype=torch.int64, device=dev if a.backend == "nccl" else "cpu")
+        allr = torch.empty(world * 3, dtype=torch.int64, device=t.device)
+        dist.all_gather_into_tensor(allr, t)
+        rank_info = allr.cpu().reshape(world, 3).tolist()
+        if sorted(r[0] for r in rank_info) != list(range(world)):
+            raise SystemExit(f"bench.py: ranks seen {rank_info}, expected 0..{world - 1}")
 
     if rank == 0:
         res = {
             "metric": "encode+decode GB/s (int16 in)",
             "value": world * raw_bytes * a.steps / dt / 1e9,
             "unit": "GB/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "n_gpus": world, "ranks_seen": len(rank_info), "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int16", "data": "synthetic",
@@ -226,6 +297,8 @@ def main():
                        "waveforms_per_gpu": n_waves, "wave_len": L, "rice_m": a.m, "chunks_per_gpu": n_chunks,
                        "decode_impl": a.decode_impl},
             "compression_ratio": ratio,
+            "rank_devices": [r[1] for r in rank_info], "rank_encoded_bytes": [r[2] for r in rank_info],
+            "backend": (a.backend if world > 1 else None),
             "encode_GBps": raw_bytes / (enc_ms[3] * 1e-3) / 1e9,
             "decode_GBps": raw_bytes / (dec_ms[3] * 1e-3) / 1e9,
             # HIP events on the codec's stream.  encode: [state memset | - | k_encode_fused];
@@ -233,11 +306,11 @@ def main():
             "kernel_ms": {"encode_prepare": float(enc_ms[0] + enc_ms[1]), "encode_kernel": float(enc_ms[2]),
                           "decode_prepare": float(dec_ms[0]), "decode_kernel": float(dec_ms[1])},
             "roofline": {"bound": "hbm", "kernel": "k_decode_lanes", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": dec_kernel_ms},
             "roofline_encode": {"bound": "hbm", "kernel": "k_encode_fused", "achieved": algo_bytes / (pack_ms * 1e-3) / 1e9,
                                 "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                "frac": algo_bytes / (pack_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic_enc,
+                                "frac": algo_bytes / (pack_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic_enc, "traffic_source": traffic_source,
                                 "kernel_ms": pack_ms},
         }
         if world == 1 and a.cpu_seconds > 0:

@@ -194,6 +194,8 @@ def _load_ref(which: str):
         _libc.malloc.restype = C.c_void_p
         _libc.malloc.argtypes = [C.c_size_t]
         _libc.free.argtypes = [C.c_void_p]
+        _libc.realloc.restype = C.c_void_p
+        _libc.realloc.argtypes = [C.c_void_p, C.c_size_t]
     return _ref[which]
 
 

@@ -71,3 +71,19 @@ def test_sharded_encode_is_byte_identical(tmp_path, world, n_chunks):
     for p in parts:
         f, c = int(p["first"]), int(p["count"])
         assert np.array_equal(p["goff"], ref_off[f:f + c + 1].astype(np.int64)), "global chunk offsets differ"
+
+
+def test_bench_gpus_n_without_devices_fails_loudly():
+    """`python bench.py --gpus N` is the driver's multi-GPU command: with fewer than N devices it must exit
+    non-zero and print no JSON line (it used to run one rank and report n_gpus: 1)."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this host has the GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--cpu-seconds", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "visible GPUs" in r.stderr + r.stdout
+    assert not any(ln.startswith("{") for ln in r.stdout.splitlines())

@@ -17,8 +17,17 @@ HIP_HDRS  := $(CSRC)/drx_internal.h include/deltarice_hip.h
 
 H5IO      := deltarice_amd/libdeltarice_h5io.so
 
-.PHONY: all hip plugin h5io oracle clean
-all: hip plugin h5io
+# Python binding (the reference's `deltaRice.h5`, src/h5.pyx) and the install step of its setup.py
+# (`install --h5plugin --h5plugin-dir=DIR`, setup.py:186-227; default dir = setup.py:44)
+PYTHON    ?= python3
+CYTHON    ?= cython
+PY_SUFFIX := $(shell $(PYTHON) -c "import sysconfig; print(sysconfig.get_config_var('EXT_SUFFIX'))")
+PY_INC    := $(shell $(PYTHON) -c "import sysconfig; print(sysconfig.get_paths()['include'])")
+PYEXT     := deltaRice/h5$(PY_SUFFIX)
+PLUGIN_DIR ?= /usr/local/hdf5/lib/plugin
+
+.PHONY: all hip plugin h5io pyext install-plugin oracle clean
+all: hip plugin h5io pyext
 
 hip: $(HIP_LIB)
 $(HIP_LIB): $(HIP_SRCS) $(HIP_HDRS)
@@ -37,9 +46,27 @@ $(H5IO): $(CSRC)/h5_direct.c include/deltarice_h5io.h include/deltarice_hip.h $(
 	    -Ldeltarice_amd -ldeltarice_hip -L$(HDF5_DIR)/lib -lhdf5 -L/opt/rocm/lib -lamdhip64 -ldl \
 	    -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(HDF5_DIR)/lib -Wl,-rpath,/opt/rocm/lib
 
+# deltaRice/h5.pyx -> deltaRice/h5.cpython-*.so, linked against the plugin library (whose callback runs the HIP codec).
+# h5py is needed to IMPORT the module, not to build it.
+pyext: $(PYEXT)
+$(PYEXT): deltaRice/h5.pyx include/deltarice_h5filter.h $(PLUGIN)
+	@mkdir -p build/pyext
+	$(CYTHON) -3 -o build/pyext/h5.c deltaRice/h5.pyx
+	$(CC) -O2 -fPIC -shared -Wall -Wno-unused-function -I$(PY_INC) -Iinclude -I$(HDF5_DIR)/include build/pyext/h5.c -o $@ \
+	    -Ldeltarice_amd/plugin -l:libh5deltarice.so -Wl,-rpath,'$$ORIGIN/../deltarice_amd/plugin'
+
+# Copies the filter plugin to where HDF5 looks for plugins (HDF5_PLUGIN_PATH, default /usr/local/hdf5/lib/plugin)
+# and the codec library one directory above it, where the plugin's $ORIGIN/.. run path finds it.
+install-plugin: $(PLUGIN) $(HIP_LIB)
+	install -d $(PLUGIN_DIR)
+	install -m 755 $(PLUGIN) $(PLUGIN_DIR)/libh5deltarice.so
+	install -m 755 $(HIP_LIB) $(PLUGIN_DIR)/../libdeltarice_hip.so
+	@echo "Installed HDF5 filter plugins to $(PLUGIN_DIR)"
+
 oracle:
 	$(MAKE) -C oracle all
 
 clean:
-	rm -f $(HIP_LIB) $(PLUGIN) $(H5IO)
+	rm -f $(HIP_LIB) $(PLUGIN) $(H5IO) $(PYEXT)
+	rm -rf build/pyext
 	$(MAKE) -C oracle clean

@@ -7,6 +7,7 @@
  * the reference links against this library unchanged:
  *
  *   H5Z_FILTER_DELTARICE          src/deltaRice.h:7        filter id 32025
+ *   superint                      src/deltaRice.h:8        the 64-bit bit-accumulator type of the CPU codec
  *   H5Z_DELTARICE[1]              src/deltaRice.c:19-28    H5Z_class2_t record
  *   H5Z_filter_deltarice          src/deltaRice.c:468-490  the H5Z_func_t callback
  *   deltarice_register_h5filter   src/deltaRice.c:494-501  explicit registration
@@ -35,6 +36,10 @@
 #include "hdf5.h"
 
 #define H5Z_FILTER_DELTARICE 32025
+/* Exported by the reference's public header (src/deltaRice.h:8; the accumulator of
+ * compressWithRiceCoding, src/deltaRice.c:194).  Nothing here uses it -- the bit packing happens in the
+ * HIP kernels -- but code that includes the reference's header may name the type. */
+typedef unsigned long long int superint;
 
 #ifdef __cplusplus
 extern "C" {

@@ -7,9 +7,10 @@ gfx950 corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 128-byt
 and against the known size of the stream each kernel reads exactly once; WRITE_SIZE is exact for
 16-byte-per-lane streaming stores.  Both are in KB.
 
-usage: make_traffic_json.py out.json counter_collection.csv [...]"""
+usage: make_traffic_json.py out.json counter_collection.csv [...]     (DRX_TRAFFIC_SOURCE: the "source" string)"""
 import csv
 import json
+import os
 import sys
 from collections import defaultdict
 
@@ -36,6 +37,6 @@ for k, c in acc.items():
         e["hbm_bytes"] = e["hbm_read_bytes"] + e["hbm_write_bytes"]
     e["raw_counters"] = m
     out[k] = e
-json.dump({"source": "rocprofv3 --pmc, bench.py default workload (1M x 7000, m=8), one MI355X",
+json.dump({"source": os.environ.get("DRX_TRAFFIC_SOURCE", "rocprofv3 --pmc, bench.py default workload (1M x 7000, m=8), one MI355X"),
            "kernels": out}, open(sys.argv[1], "w"), indent=1)
 print(json.dumps({k: {a: b for a, b in v.items() if a != "raw_counters"} for k, v in out.items()}, indent=1))

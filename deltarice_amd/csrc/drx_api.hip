@@ -42,8 +42,28 @@ struct drx_ctx {
     drx_plan *host_plan = nullptr;
     uint32_t hp_samples = 0, hp_L = 0, hp_k = 0, hp_ntaps = 0;
     int32_t hp_taps[DRX_MAX_TAPS] = {0};
-    std::mutex mu;
+    std::mutex mu;      // serialises drx_filter_chunk_host callers (HDF5 may call the filter from any thread)
+    std::mutex err_mu;  // last_error
 };
+
+// Every entry point runs on the context's device and leaves the calling thread's current device as it found it
+// (an application that works on another GPU must not find its device switched by an H5Dread).
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        err = (prev == device) ? hipSuccess : hipSetDevice(device);
+        if (prev == device) prev = -1;  // nothing to restore
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define DRX_ON_DEVICE(ctx)                                                                         \
+    DeviceGuard dev_guard_((ctx)->device);                                                         \
+    if (dev_guard_.err != hipSuccess)                                                              \
+        return fail((ctx), DRX_ERR_DEVICE, "hipSetDevice(%d) failed: %s", (ctx)->device, hipGetErrorString(dev_guard_.err))
 
 struct drx_plan {
     drx_ctx *ctx = nullptr;
@@ -77,7 +97,10 @@ static drx_status fail(drx_ctx *ctx, drx_status st, const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (ctx) ctx->last_error = buf;
+    if (ctx) {
+        std::lock_guard<std::mutex> lock(ctx->err_mu);
+        ctx->last_error = buf;
+    }
     return st;
 }
 
@@ -147,7 +170,8 @@ drx_status drx_ctx_create(int device, void *hip_stream, drx_ctx **out) {
     drx_ctx *c = new (std::nothrow) drx_ctx;
     if (!c) return DRX_ERR_NOMEM;
     c->device = device;
-    if (hipSetDevice(device) != hipSuccess) { delete c; return DRX_ERR_DEVICE; }
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) { delete c; return DRX_ERR_DEVICE; }
     if (hip_stream) {
         c->stream = (hipStream_t)hip_stream;
     } else {
@@ -162,7 +186,7 @@ static void plan_free(drx_plan *p);
 
 void drx_ctx_destroy(drx_ctx *c) {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    DeviceGuard guard(c->device);
     if (c->host_plan) plan_free(c->host_plan);
     if (c->d_raw) (void)hipFree(c->d_raw);
     if (c->d_enc) (void)hipFree(c->d_enc);
@@ -174,6 +198,7 @@ void drx_ctx_destroy(drx_ctx *c) {
 
 drx_status drx_ctx_synchronize(drx_ctx *c) {
     if (!c) return DRX_ERR_ARG;
+    DRX_ON_DEVICE(c);
     DRX_HIP(c, hipStreamSynchronize(c->stream));
     return DRX_OK;
 }
@@ -206,7 +231,7 @@ drx_status drx_ctx_set_option(drx_ctx *c, const char *key, int64_t value) {
 
 static void plan_free(drx_plan *p) {
     if (!p) return;
-    (void)hipSetDevice(p->ctx->device);
+    DeviceGuard guard(p->ctx->device);
     if (p->d_chunks) (void)hipFree(p->d_chunks);
     if (p->d_wave_words) (void)hipFree(p->d_wave_words);
     if (p->d_wave_rel) (void)hipFree(p->d_wave_rel);
@@ -227,7 +252,7 @@ static void plan_free(drx_plan *p) {
 }
 
 static drx_status plan_alloc(drx_ctx *ctx, drx_plan *p) {
-    DRX_HIP(ctx, hipSetDevice(ctx->device));
+    DRX_ON_DEVICE(ctx);
     const uint64_t W = p->G.total_waves ? p->G.total_waves : 1;
     DRX_HIP(ctx, hipMalloc((void **)&p->d_wave_words, W * sizeof(uint32_t)));
     DRX_HIP(ctx, hipMalloc((void **)&p->d_wave_rel, W * sizeof(uint32_t)));
@@ -238,6 +263,19 @@ static drx_status plan_alloc(drx_ctx *ctx, drx_plan *p) {
     DRX_HIP(ctx, hipHostMalloc((void **)&p->h_status, sizeof(DevStatus), hipHostMallocDefault));
     memset(p->h_status, 0, sizeof(DevStatus));
     for (hipEvent_t &e : p->ev) DRX_HIP(ctx, hipEventCreate(&e));
+    return DRX_OK;
+}
+
+// Scratch that only some geometries need (segment encoder, long-waveform decoder, parallel header walks): allocated
+// with the plan, so that drx_encode / drx_decode never allocate.
+static drx_status plan_alloc_scratch(drx_ctx *ctx, drx_plan *p) {
+    if (long_batch(p->G)) {
+        const uint64_t units = long_batch_units(p->G);
+        DRX_HIP(ctx, hipMalloc((void **)&p->d_seg_bits, units * sizeof(uint32_t)));
+        DRX_HIP(ctx, hipMalloc((void **)&p->d_seg_pos, units * sizeof(uint64_t)));
+    }
+    if (const uint64_t nb = long_decode_scratch_bytes(p->G)) DRX_HIP(ctx, hipMalloc((void **)&p->d_long, nb));
+    if (const uint64_t nb = par_walk_scratch_bytes(p->G)) DRX_HIP(ctx, hipMalloc(&p->d_pw, nb));
     return DRX_OK;
 }
 
@@ -331,6 +369,7 @@ drx_status drx_plan_create(drx_ctx *ctx, uint64_t n_chunks, const uint32_t *chun
     }
     if (st != DRX_OK) { plan_free(p); return st; }
     p->G.chunks = p->d_chunks;
+    if ((st = plan_alloc_scratch(ctx, p)) != DRX_OK) { plan_free(p); return st; }
     *out = p;
     return DRX_OK;
 }
@@ -359,6 +398,7 @@ drx_status drx_plan_create_uniform(drx_ctx *ctx, uint64_t n_chunks, uint32_t chu
     p->G.u_n_waves = W;
     p->G.k = rice_k;
     drx_status st = plan_alloc(ctx, p);
+    if (st == DRX_OK) st = plan_alloc_scratch(ctx, p);
     if (st != DRX_OK) { plan_free(p); return st; }
     *out = p;
     return DRX_OK;
@@ -368,7 +408,7 @@ drx_status drx_plan_set_filter(drx_plan *p, uint32_t n_taps, const int32_t *taps
     if (!p || !taps || n_taps == 0 || n_taps > DRX_MAX_TAPS) return DRX_ERR_ARG;
     drx_ctx *ctx = p->ctx;
     if (taps[0] == 0) return fail(ctx, DRX_ERR_ARG, "taps[0] must not be 0 (the inverse filter divides by it)");
-    DRX_HIP(ctx, hipSetDevice(ctx->device));
+    DRX_ON_DEVICE(ctx);
     DRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     p->G.fast_taps = 0;
     p->G.enc_fast = 0;
@@ -404,7 +444,7 @@ const uint64_t *drx_plan_wave_word_off(const drx_plan *p) { return p ? p->d_wave
 drx_status drx_plan_read_wave_words(drx_plan *p, uint32_t *host_out) {
     if (!p || !host_out) return DRX_ERR_ARG;
     drx_ctx *ctx = p->ctx;
-    DRX_HIP(ctx, hipSetDevice(ctx->device));
+    DRX_ON_DEVICE(ctx);
     DRX_HIP(ctx, hipMemcpyAsync(host_out, p->d_wave_words, p->G.total_waves * sizeof(uint32_t),
                                 hipMemcpyDeviceToHost, ctx->stream));
     DRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -415,11 +455,11 @@ drx_status drx_encode(drx_plan *p, const int16_t *d_in, uint32_t *d_out, uint64_
                       uint64_t *d_chunk_word_off) {
     if (!p || !d_in || !d_out || !d_chunk_word_off) return DRX_ERR_ARG;
     drx_ctx *ctx = p->ctx;
-    DRX_HIP(ctx, hipSetDevice(ctx->device));
+    DRX_ON_DEVICE(ctx);
     DRX_HIP(ctx, hipMemsetAsync(p->d_status, 0, sizeof(DevStatus), ctx->stream));
     p->G.dbg = ctx->debug_flags;
     if (ctx->encode_impl == 1 && long_batch(p->G) && !(ctx->debug_flags & 256u)) {
-        if (!p->d_seg_bits) {
+        if (!p->d_seg_bits) {  // only when a diagnostic debug_flags value forces this path on a geometry that does not take it
             const uint64_t units = long_batch_units(p->G);
             DRX_HIP(ctx, hipMalloc((void **)&p->d_seg_bits, units * sizeof(uint32_t)));
             DRX_HIP(ctx, hipMalloc((void **)&p->d_seg_pos, units * sizeof(uint64_t)));
@@ -443,17 +483,11 @@ static drx_status decode_launch(drx_plan *p, const uint32_t *d_in, uint64_t in_w
                                 const uint64_t *d_chunk_word_off, int16_t *d_out, bool tables_ready) {
     if (!p || !d_in || !d_chunk_word_off || !d_out) return DRX_ERR_ARG;
     drx_ctx *ctx = p->ctx;
-    DRX_HIP(ctx, hipSetDevice(ctx->device));
+    DRX_ON_DEVICE(ctx);
     DRX_HIP(ctx, hipMemsetAsync(p->d_status, 0, sizeof(DevStatus), ctx->stream));
     p->G.dbg = ctx->debug_flags;
-    if (!p->d_long) {
-        const uint64_t nb = long_decode_scratch_bytes(p->G);
-        if (nb) DRX_HIP(ctx, hipMalloc((void **)&p->d_long, nb));
-    }
-    if (!p->d_pw) {
-        const uint64_t nb = par_walk_scratch_bytes(p->G);
-        if (nb) DRX_HIP(ctx, hipMalloc(&p->d_pw, nb));
-    }
+    // (d_long / d_pw were allocated with the plan; a plan whose filter was set to general taps afterwards simply does
+    // not take those paths)
     DRX_HIP(ctx, launch_decode(p->G, d_in, in_words, d_chunk_word_off, d_out, p->d_wave_off,
                                p->d_wave_words, p->d_scan, p->d_status,
                                (tables_ready ? 100 : 0) + ctx->decode_impl, p->d_long, p->d_pw,
@@ -469,8 +503,8 @@ drx_status drx_decode(drx_plan *p, const uint32_t *d_in, uint64_t in_words,
 }
 
 // Header chain of ONE encoded chunk in host memory (src/deltaRice.c:320-325), with the validation the device
-// walk does: sample count, every n_i within 25 bits per sample, the chain ends exactly at the chunk end.
-static bool walk_chunk_host(const uint32_t *w, uint64_t n_words, uint32_t n_samples, uint32_t wave_len,
+// walk does: sample count, every n_i between 1 + k and 25 bits per sample, the chain ends exactly at the chunk end.
+static bool walk_chunk_host(const uint32_t *w, uint64_t n_words, uint32_t n_samples, uint32_t wave_len, uint32_t k,
                             uint64_t *wave_off, uint32_t *wave_words) {
     if (n_words < 2 || w[0] != n_samples) return false;
     const uint32_t L = wave_len ? wave_len : n_samples;
@@ -480,7 +514,7 @@ static bool walk_chunk_host(const uint32_t *w, uint64_t n_words, uint32_t n_samp
         if (at >= n_words) return false;
         const uint32_t n = w[at];
         const uint64_t len = (i + 1 == W) ? (uint64_t)n_samples - i * L : L;
-        if (n > ((len * 25u + 31u) >> 5) || at + 1u + n > n_words) return false;
+        if (n > ((len * 25u + 31u) >> 5) || n < ((len * (k + 1u) + 31u) >> 5) || at + 1u + n > n_words) return false;
         wave_off[i] = at;
         wave_words[i] = n;
         at += (uint64_t)n + 1u;
@@ -491,7 +525,7 @@ static bool walk_chunk_host(const uint32_t *w, uint64_t n_words, uint32_t n_samp
 drx_status drx_estimate_words(drx_plan *p, const int16_t *d_in, uint64_t words_out[16]) {
     if (!p || !d_in || !words_out) return DRX_ERR_ARG;
     drx_ctx *ctx = p->ctx;
-    DRX_HIP(ctx, hipSetDevice(ctx->device));
+    DRX_ON_DEVICE(ctx);
     // the look-back scratch is idle outside drx_encode/drx_decode: its first 16 words hold the sums
     DRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     DRX_HIP(ctx, launch_estimate_words(p->G, d_in, (unsigned long long *)p->d_scan, ctx->stream));
@@ -504,7 +538,7 @@ drx_status drx_plan_last_timings(drx_plan *p, float ms[4]) {
     if (!p || !ms) return DRX_ERR_ARG;
     drx_ctx *ctx = p->ctx;
     if (!p->ev_valid) return fail(ctx, DRX_ERR_ARG, "set the context option \"profile\" before the call to be timed");
-    DRX_HIP(ctx, hipSetDevice(ctx->device));
+    DRX_ON_DEVICE(ctx);
     DRX_HIP(ctx, hipEventSynchronize(p->ev[3]));
     for (int i = 0; i < 3; ++i) DRX_HIP(ctx, hipEventElapsedTime(&ms[i], p->ev[i], p->ev[i + 1]));
     DRX_HIP(ctx, hipEventElapsedTime(&ms[3], p->ev[0], p->ev[3]));
@@ -514,7 +548,7 @@ drx_status drx_plan_last_timings(drx_plan *p, float ms[4]) {
 drx_status drx_plan_finish(drx_plan *p, uint64_t *total_words) {
     if (!p) return DRX_ERR_ARG;
     drx_ctx *ctx = p->ctx;
-    DRX_HIP(ctx, hipSetDevice(ctx->device));
+    DRX_ON_DEVICE(ctx);
     DRX_HIP(ctx, hipMemcpyAsync(p->h_status, p->d_status, sizeof(DevStatus), hipMemcpyDeviceToHost, ctx->stream));
     DRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (total_words) *total_words = p->h_status->total_words;
@@ -545,7 +579,7 @@ drx_status drx_filter_chunk_host(drx_ctx *ctx, int reverse, size_t cd_nelmts, co
     if (drx_parse_cd_values(cd_nelmts, cd_values, &o) != DRX_OK)
         return fail(ctx, DRX_ERR_ARG, "invalid compression_opts");
     std::lock_guard<std::mutex> lock(ctx->mu);
-    DRX_HIP(ctx, hipSetDevice(ctx->device));
+    DRX_ON_DEVICE(ctx);
     if (!ctx->d_off) DRX_HIP(ctx, hipMalloc((void **)&ctx->d_off, 2 * sizeof(uint64_t)));
 
     uint32_t n_samples;
@@ -557,6 +591,10 @@ drx_status drx_filter_chunk_host(drx_ctx *ctx, int reverse, size_t cd_nelmts, co
         if (nbytes < 8 || (nbytes & 3u)) return fail(ctx, DRX_ERR_CORRUPT, "encoded chunk of %zu bytes", nbytes);
         memcpy(&n_samples, in, 4);  // totalNumberPoints (:306)
         if (n_samples == 0 || n_samples > 0x7fffffffu) return fail(ctx, DRX_ERR_CORRUPT, "bad sample count in header");
+        // the header is untrusted and sizes every allocation below: a code has at least 1 + k bits (:215-222), so a
+        // chunk of nbytes cannot hold more than 8 * (nbytes - 8) / (1 + k) samples
+        if ((uint64_t)(nbytes - 8) * 8u < (uint64_t)n_samples * (o.rice_k + 1u))
+            return fail(ctx, DRX_ERR_CORRUPT, "header claims %u samples, %zu bytes cannot hold them", n_samples, nbytes);
     }
     const uint32_t L = (o.wave_len < 0) ? 0u : (uint32_t)o.wave_len;
     drx_status st = DRX_OK;
@@ -605,10 +643,12 @@ drx_status drx_filter_chunk_host(drx_ctx *ctx, int reverse, size_t cd_nelmts, co
             if (e != hipSuccess) { st = fail(ctx, DRX_ERR_DEVICE, "D2H failed: %s", hipGetErrorString(e)); break; }
             *out_bytes = nb;
         } else {
-            // the chunk goes to the device while the CPU walks its header chain: 2000 dependent loads are
-            // 1.7 ms of HBM round trips on the GPU and ~0.1 ms out of host memory
+            // The device finds the headers (parallel walk: 0.14 ms for one chunk).  DRX_HOST_WALK=1 walks the chain on
+            // the CPU instead while the chunk travels (0.28 ms; the faster way before the parallel walk existed) and
+            // uploads the tables.
             const uint64_t W = plan->G.total_waves;
-            const size_t tab_bytes = 16 + (size_t)W * (sizeof(uint64_t) + sizeof(uint32_t));
+            static const bool device_walk = getenv("DRX_HOST_WALK") == nullptr;
+            const size_t tab_bytes = 16 + (device_walk ? 0 : (size_t)W * (sizeof(uint64_t) + sizeof(uint32_t)));
             if ((st = grow(ctx, &ctx->h_pin, &ctx->pin_cap, tab_bytes, true)) != DRX_OK) break;
             uint64_t *h_off = (uint64_t *)ctx->h_pin;              // [2] chunk table, then [W] wave_off
             uint32_t *h_words = (uint32_t *)(h_off + 2 + W);       // [W] wave_words
@@ -616,22 +656,20 @@ drx_status drx_filter_chunk_host(drx_ctx *ctx, int reverse, size_t cd_nelmts, co
             h_off[1] = (uint64_t)(nbytes / 4);
             e = hipMemcpyAsync(ctx->d_enc, in, nbytes, hipMemcpyHostToDevice, ctx->stream);
             lap("decode: H2D chunk");
-            // The device finds the headers (parallel walk: 0.14 ms for one chunk); DRX_HOST_WALK=1 walks the chain on the
-            // CPU instead, which was the faster way (0.28 ms against 1.7 ms) before the parallel walk existed.
-            static const bool device_walk = getenv("DRX_HOST_WALK") == nullptr;
-            if (!device_walk && !walk_chunk_host((const uint32_t *)in, nbytes / 4, n_samples, L, h_off + 2, h_words)) {
-                (void)hipStreamSynchronize(ctx->stream);
-                st = fail(ctx, DRX_ERR_CORRUPT, "encoded chunk failed header-chain validation");
-                break;
-            }
-            lap("decode: host walk");
             if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_off, h_off, 2 * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(plan->d_wave_off, h_off + 2, W * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(plan->d_wave_words, h_words, W * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
-            lap("decode: H2D tables");
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the pinned table is reused by the next call
+            if (!device_walk) {
+                if (!walk_chunk_host((const uint32_t *)in, nbytes / 4, n_samples, L, o.rice_k, h_off + 2, h_words)) {
+                    (void)hipStreamSynchronize(ctx->stream);
+                    st = fail(ctx, DRX_ERR_CORRUPT, "encoded chunk failed header-chain validation");
+                    break;
+                }
+                lap("decode: host walk");
+                if (e == hipSuccess) e = hipMemcpyAsync(plan->d_wave_off, h_off + 2, W * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(plan->d_wave_words, h_words, W * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+                lap("decode: H2D tables");
+            }
+            // (no wait here: the pinned table is not touched again before this call's final synchronisation)
             if (e != hipSuccess) { st = fail(ctx, DRX_ERR_DEVICE, "H2D failed: %s", hipGetErrorString(e)); break; }
-            lap("decode: H2D sync");
             if ((st = decode_launch(plan, (const uint32_t *)ctx->d_enc, nbytes / 4, ctx->d_off, (int16_t *)ctx->d_raw, !device_walk)) != DRX_OK) break;
             if ((st = drx_plan_finish(plan, nullptr)) != DRX_OK) break;
             lap("decode: kernels + finish");

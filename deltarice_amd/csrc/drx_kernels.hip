@@ -65,6 +65,21 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return v;
 }
 
+// Bounds on a waveform's payload word count n_i: a code has between 1 + k (q = 0, src/deltaRice.c:215-222) and 25 bits
+// (escape, :223-228).  Every walker rejects a header outside [min, max]: the chain of a valid stream never leaves them.
+__host__ __device__ __forceinline__ uint32_t max_payload_words(uint32_t len) { return (uint32_t)(((uint64_t)len * 25u + 31u) >> 5); }
+__host__ __device__ __forceinline__ uint32_t min_payload_words(uint32_t len, uint32_t k) {
+    return (uint32_t)(((uint64_t)len * (k + 1u) + 31u) >> 5);
+}
+
+// count-leading-zeros with the ISA's result for 0 (-1) instead of the source language's undefined behaviour: the
+// decoders meet an all-zero window only past the end of a corrupt stream, where any value will do, but it has to BE a value
+__device__ __forceinline__ uint32_t ffbh(uint32_t x) {
+    uint32_t r;
+    asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 struct WaveRef {
     uint64_t chunk;       // chunk index
     uint64_t sample_off;  // first sample of this waveform in the raw batch
@@ -1046,8 +1061,7 @@ __device__ __forceinline__ void walk_chunk(const Geom &G, uint64_t c, const uint
         if (!bad && at < end) {
             n = in[at];
             const uint32_t len = (w + 1 == W) ? (N - w * L) : L;
-            const uint64_t max_words = ((uint64_t)len * 25u + 31u) >> 5;
-            if (n > max_words || at + 1u + n > end) { bad = true; n = 0; }
+            if (n > max_payload_words(len) || n < min_payload_words(len, G.k) || at + 1u + n > end) { bad = true; n = 0; }
             else at += (uint64_t)n + 1u;
         } else {
             bad = true;
@@ -1146,8 +1160,7 @@ __device__ __forceinline__ void walk_chunks_scalar(const Geom &G, uint64_t c0, c
         if (can) {
             n = nn;
             const uint32_t len = (w + 1 == W) ? (N - w * L) : L;
-            const uint64_t max_words = ((uint64_t)len * 25u + 31u) >> 5;
-            if (n > max_words || at + 1u + n > end) { bad = true; n = 0; }
+            if (n > max_payload_words(len) || n < min_payload_words(len, G.k) || at + 1u + n > end) { bad = true; n = 0; }
             else at += (uint64_t)n + 1u;
         } else if (live) {
             bad = true;
@@ -1298,6 +1311,7 @@ __global__ __launch_bounds__(kPwThreads) void k_walk_parallel(Geom G, const uint
     const uint32_t len_w = (uint32_t)(end - begin);  // words in the chunk
     const uint32_t max_full = (uint32_t)(((uint64_t)L * 25u + 31u) >> 5);
     const uint32_t max_last = (uint32_t)(((uint64_t)(N - (W - 1) * L) * 25u + 31u) >> 5);
+    const uint32_t min_full = min_payload_words(L, G.k), min_last = min_payload_words(N - (W - 1) * L, G.k);
     const uint32_t nc = cand_count[c];
     if (nc > kPwCap - 2u || nc < W) { if (tid == 0) fail[c] = 1u; return; }
     for (uint32_t i = tid; i < kPwCap; i += kPwThreads) {
@@ -1357,7 +1371,7 @@ __global__ __launch_bounds__(kPwThreads) void k_walk_parallel(Geom G, const uint
             if ((w >> k) & 1u) node = up[k][node];
         if (node >= nc) { bad = true; continue; }
         const uint32_t n = val[node];
-        if (n > ((w + 1u == W) ? max_last : max_full)) { bad = true; continue; }
+        if (n > ((w + 1u == W) ? max_last : max_full) || n < ((w + 1u == W) ? min_last : min_full)) { bad = true; continue; }
         if (w + 1u == W && up[0][node] != END) { bad = true; continue; }
         wave_off[base + w] = begin + pos[node];
         wave_words[base + w] = n;
@@ -1415,6 +1429,7 @@ __device__ __forceinline__ void walk_chunk_block(const Geom &G, uint64_t c, cons
     if (!bad && in[begin] != N) bad = true;
     const uint32_t max_full = (uint32_t)(((uint64_t)L * 25u + 31u) >> 5);
     const uint32_t max_last = W ? (uint32_t)(((uint64_t)(N - (W - 1) * L) * 25u + 31u) >> 5) : 0u;
+    const uint32_t min_full = min_payload_words(L, G.k), min_last = W ? min_payload_words(N - (W - 1) * L, G.k) : 0u;
     // blocks on a fixed grid from g0 (16-byte aligned when the stream is), so that block k + 1 can be
     // requested before the chase through block k starts
     const bool vec_ok = ((uintptr_t)in & 15u) == 0;
@@ -1458,8 +1473,8 @@ __device__ __forceinline__ void walk_chunk_block(const Geom &G, uint64_t c, cons
             uint32_t hops = 0;
             while (w < W && rel < blk_len && hops < kWalkHopCap) {
                 const uint32_t n = __builtin_amdgcn_readfirstlane(blk[rel]);
-                const uint32_t lim = (w + 1 == W) ? max_last : max_full;
-                if (n > lim || rel + 1u + n > end_rel) { bad = true; break; }
+                const uint32_t lim = (w + 1 == W) ? max_last : max_full, lim_lo = (w + 1 == W) ? min_last : min_full;
+                if (n > lim || n < lim_lo || rel + 1u + n > end_rel) { bad = true; break; }
                 hop[hops] = make_uint2(rel, n);
                 rel += n + 1u;
                 ++w;
@@ -1626,10 +1641,13 @@ __global__ __launch_bounds__(64) void k_bw_blocks(Geom G, const uint32_t *__rest
             const uint2 h = hop[i];
             wave_off[base + w0 + i] = begin + b0 + h.x;
             wave_words[base + w0 + i] = h.y;
-            // the chunk's last waveform may be shorter than the rest: its header has a tighter bound
+            // the chunk's last waveform may be shorter than the rest: its header has tighter bounds; and no
+            // header may be below the minimum of 1 + k bits per sample (the chase only checked the upper bound)
             if (info[unit].base + w0 + i + 1u == W) {
-                const uint32_t max_last = (uint32_t)(((uint64_t)(n_samples - (W - 1u) * L) * 25u + 31u) >> 5);
-                if (h.y > max_last) atomicOr(&st->err, kErrCorrupt);
+                const uint32_t last_len = n_samples - (W - 1u) * L;
+                if (h.y > max_payload_words(last_len) || h.y < min_payload_words(last_len, G.k)) atomicOr(&st->err, kErrCorrupt);
+            } else if (h.y < min_payload_words(L, G.k)) {
+                atomicOr(&st->err, kErrCorrupt);
             }
         }
         wave_sync();

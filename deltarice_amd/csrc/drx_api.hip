@@ -26,8 +26,8 @@ struct drx_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int decode_impl = 8;   // launch_decode(): 8 = walk fused into the staged kernel, two samples per ring access
-                           // (default; uniform batches), 7 = the same with a separate walk kernel, 5/1 = one sample
-                           // per ring access (fused / separate walk), 2-4, 6, 9-13 = other geometries, 0 = simple kernel
+                           // (default), 7 = the same with a separate walk kernel, 5 / 1 = one sample per ring access
+                           // (fused / separate walk), 0 = simple kernel
     int encode_impl = 1;  // 1: single pass with look-back (k_encode_fused), 0: size pass + scan + pack pass
     int profile = 0;      // bracket kernels with HIP events (drx_plan_last_timings)
     uint32_t debug_flags = 0;  // Geom::dbg
@@ -209,7 +209,7 @@ void *drx_ctx_stream(const drx_ctx *c) { return c ? (void *)c->stream : nullptr;
 drx_status drx_ctx_set_option(drx_ctx *c, const char *key, int64_t value) {
     if (!c || !key) return DRX_ERR_ARG;
     if (!strcmp(key, "decode_impl")) {
-        if (value < 0 || value > 17) return DRX_ERR_ARG;
+        if (value != 0 && value != 1 && value != 5 && value != 7 && value != 8) return DRX_ERR_ARG;
         c->decode_impl = (int)value;
         return DRX_OK;
     }

@@ -37,13 +37,13 @@ struct Geom {
     // forward filter in the single-pass encoder: at most 4 taps, any taps[0]; enc_t[j] = taps[j] mod 2^16
     uint32_t enc_fast;
     uint32_t enc_t[4];
-    uint32_t dbg;  // ablation / A-B switches ("debug_flags" context option; 0 in normal use, results are
-                   // invalid with bits 0, 1, 5, 6, 7):
-                   //   decode:   1 skip the output stores        2 skip the stream loads
-                   //             4 request pieces without counting on the round's minimum consumption
-                   //             8 walk with vector loads, 64 chunks per wave (the pre-scalar-load walk)
-                   //           256 never take the long-waveform paths   512 long waveforms: one workgroup per waveform only
-                   //          2048 never take the parallel header walk of small batches
+    uint32_t dbg;  // "debug_flags" context option; 0 in normal use.  Dispatch overrides (host side, always available, every
+                   // forced path is bit-exact and the tests use them to reach it):
+                   //   256 never take the long-waveform paths   512 long waveforms: one workgroup per waveform only
+                   //  2048 never take the parallel header walks of small batches   8192 always the segment encoder
+                   // Ablation switches INSIDE the kernels, compiled only with -DDRX_ABLATION (results invalid):
+                   //   decode:   1 skip the output stores   2 skip the stream loads
+                   //             4 request pieces without counting on the round's minimum consumption   16384 long: no stores
                    //   encode:  16 per-code LDS emission instead of the lane-local concatenation
                    //            32 no emission   64 no copy-out   128 no look-back (positions wrong)
     // ragged batches, walk inside the decode launch: chunk indices, short-waveform chunks first

@@ -28,6 +28,14 @@
 
 namespace drx {
 
+// Ablation switches inside the hot loops (Geom::dbg bits 1, 2, 4, 16, 32, 64, 128) exist only in builds made with
+// -DDRX_ABLATION (loaded through DRX_LIB_PATH for A/B timing); the shipped kernels carry none of those branches.
+#ifdef DRX_ABLATION
+constexpr bool kAblate = true;
+#else
+constexpr bool kAblate = false;
+#endif
+
 // ---------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------
@@ -611,8 +619,8 @@ __global__ __launch_bounds__(64 * kEncWaves) void k_encode_fused(Geom G, const i
     const int16_t *x = in + r.sample_off;
     // 16-byte loads at any int16 alignment (unaligned access is on for HSA queues): a WaveformLength like 3500 puts
     // every other waveform 8 bytes off a 16-byte boundary, an odd one 2 bytes off a dword, and the per-sample
-    // fallback is 2x slower (dbg 4096 keeps the old 16-byte rule)
-    const bool vec_ok = (G.dbg & 4096u) ? ((uintptr_t)x & 15u) == 0 : true;
+    // fallback is 2x slower
+    const bool vec_ok = true;
     const uint32_t k = G.k;
     wave_sync();
 
@@ -646,9 +654,9 @@ __global__ __launch_bounds__(64 * kEncWaves) void k_encode_fused(Geom G, const i
         if (FULLT) concat_codes(c, cw);  // independent of the scan: fills its DPP wait states
         const uint32_t incl = wave_incl_scan_dpp(lane_bits);
         const uint32_t tile_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        if (G.dbg & 32u) {  // ablation: no emission
+        if (kAblate && (G.dbg & 32u)) {  // ablation: no emission
         } else if (fits && ((P + tile_bits + 31u) >> 5) < (uint64_t)kEncCapWords) {
-            if (FULLT && !(G.dbg & 16u) && !__any(lane_bits > 128u))
+            if (FULLT && !(kAblate && (G.dbg & 16u)) && !__any(lane_bits > 128u))
                 place_words(cw, buf_bits + (uint32_t)P + incl);
             else
                 emit_tile<FULLT>(c, buf_bits + (uint32_t)P + incl - lane_bits);
@@ -727,7 +735,7 @@ __global__ __launch_bounds__(64 * kEncWaves) void k_encode_fused(Geom G, const i
         for (int i = 0; i < kEncWaves; ++i) block_sum += s_mine[i];
         const uint64_t T = s_ticket;
         uint64_t excl_blk = 0;
-        if (T == 0 || (G.dbg & 128u)) {  // dbg 128: ablation, no look-back (positions are wrong)
+        if (T == 0 || (kAblate && (G.dbg & 128u))) {  // dbg 128: ablation, no look-back (positions are wrong)
             if (lane == 0) __hip_atomic_store(scan_state + T, kScanPrefix | block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (T) excl_blk = T * 2048ull * kEncWaves;
         } else {
@@ -788,7 +796,7 @@ __global__ __launch_bounds__(64 * kEncWaves) void k_encode_fused(Geom G, const i
     }
     uint32_t *__restrict__ outp = out + pos + 1;
     if (fits) {
-        if (!(G.dbg & 64u))
+        if (!(kAblate && (G.dbg & 64u)))
             for (uint32_t i = lane; i < n; i += 64) outp[i] = buf[i];
         return;
     }
@@ -1381,15 +1389,6 @@ __global__ __launch_bounds__(kPwThreads) void k_walk_parallel(Geom G, const uint
     if (tid == 0 && s_bad) fail[c] = 1u;
 }
 
-__global__ __launch_bounds__(64) void k_walk(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
-                                             const uint64_t *__restrict__ chunk_word_off,
-                                             uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
-                                             DevStatus *st) {
-    const uint64_t c = (uint64_t)blockIdx.x * 64u + threadIdx.x;
-    if (c >= G.n_chunks) return;
-    walk_chunk(G, c, in, in_words, chunk_word_off, wave_off, wave_words, nullptr, st);
-}
-
 __global__ __launch_bounds__(64) void k_walk_list(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
                                                   const uint64_t *__restrict__ chunk_word_off,
                                                   const uint32_t *__restrict__ chunk_list, uint32_t n_list,
@@ -1718,7 +1717,7 @@ __global__ __launch_bounds__(64) void k_walk_block_only(Geom G, const uint32_t *
 // Kept as the simple cross-check of the staged kernel below (decode_impl = 0).
 __global__ __launch_bounds__(64) void k_decode_simple(Geom G, const uint32_t *__restrict__ in,
                                                       const uint64_t *__restrict__ wave_off,
-                                                      const uint32_t *__restrict__ wave_words,
+                                                      const uint32_t *__restrict__ wave_words, DevStatus *st,
                                                       int16_t *__restrict__ out) {
     const uint64_t g = (uint64_t)blockIdx.x * 64u + threadIdx.x;
     if (g >= G.total_waves) return;
@@ -1760,6 +1759,9 @@ __global__ __launch_bounds__(64) void k_decode_simple(Geom G, const uint32_t *__
         win <<= used;
         have -= used;
     }
+    // a valid waveform's codes end in its last payload word: n_i = ceil(bits / 32) (src/deltaRice.c:237-241)
+    const uint64_t bits = 32ull * wi - have;
+    if (r.len && ((bits + 31u) >> 5) != n) atomicOr(&st->err, kErrCorrupt);
 }
 
 // Decoder for FEW, LONG waveforms (WaveformLength = -1, the reference's default, makes every chunk one
@@ -1873,14 +1875,14 @@ __global__ __launch_bounds__(kLongThreads) void k_decode_long(Geom G, const uint
                 const lds_cu32 *wp = (const lds_cu32 *)(uintptr_t)(row0 + (uint32_t)(((int32_t)Q >> 5) * (int32_t)(NT * 4u)));
                 const uint32_t lo = wp[0], hi = wp[NT];
                 const uint32_t win = __builtin_amdgcn_alignbit(hi, lo, Q);
-                const uint32_t q = (uint32_t)__builtin_clz(win);  // all-zero window (padding): the hardware's -1 is as good as any
+                const uint32_t q = ffbh(win);  // all-zero window (padding): the hardware's -1 is as good as any
                 const uint32_t kk = (win < (1u << 24)) ? 16u : k;
                 const uint32_t nu = ~(q + kk);  // minus the code length
                 const uint32_t z = (q << kk) + __builtin_amdgcn_ubfe(win, nu, kk);
                 const uint32_t d = (z >> 1) ^ (0u - (z & 1u));
                 const uint32_t s2 = sacc + d;
                 if (EMIT) {
-                    if (act && idx + c < len && !(G.dbg & 16384u)) {  // (16384: ablation, no stores)
+                    if (act && idx + c < len && !(kAblate && (G.dbg & 16384u))) {  // (16384: ablation, no stores)
                         const uint32_t i = idx + c;
                         if constexpr (QUADS) {
                             q4 = (q4 >> 16) | ((uint64_t)(s2 & 0xffffu) << 48);
@@ -2094,7 +2096,7 @@ __global__ __launch_bounds__(64) void k_long_tail(Geom G, const uint32_t *__rest
 //               so the ~1.7 ms of dependent-load latency of the walk disappears behind the decode.
 //               A ticket holder is by construction running, so waiting on a lower ticket's walker
 //               cannot deadlock whatever the dispatch order.  (Uniform batches only.)
-template <int RW, int LW, int T, int GS, bool FUSED, bool PAIR = false, bool CAP2 = false, bool GEN = false>
+template <int RW, int LW, int T, int GS, bool FUSED, bool PAIR = false, bool GEN = false>
 __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
                                                      const uint64_t *__restrict__ chunk_word_off,
                                                      uint64_t *__restrict__ wave_off,
@@ -2121,7 +2123,6 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
 
     const int lane = lane_id();
     const uint32_t k = G.k;
-    if (CAP2) asm volatile("v_mov_b32 v200, 0" ::: "v200");  // experiment: > 170 VGPRs = at most two waves per SIMD
     // Stores go through pointers with an explicit global address space: once `out` has travelled through
     // nested by-reference lambda captures the compiler no longer infers it and emits flat_store, which
     // also ticks lgkmcnt and serialises against the LDS traffic of the write-out (measured: 2x slower).
@@ -2144,14 +2145,10 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
         const bool u_short = G.uniform && G.u_wave_len <= kWalkShortLen;
         const uint32_t n_blockwalk = G.uniform ? (u_short ? (uint32_t)G.n_chunks : 0u) : G.n_short;
         const uint64_t n_chain = G.uniform ? (u_short ? 0ull : G.n_chunks) : (uint64_t)G.n_long;
-        const uint32_t n_walk = (G.dbg & 8u) ? (uint32_t)((G.n_chunks + 63u) >> 6)
-                                             : n_blockwalk + (uint32_t)((n_chain + (uint32_t)kWalkChains - 1u) / (uint32_t)kWalkChains);
+        const uint32_t n_walk = n_blockwalk + (uint32_t)((n_chain + (uint32_t)kWalkChains - 1u) / (uint32_t)kWalkChains);
         if (tk < n_walk) {  // walker role
             __builtin_amdgcn_s_setprio(3);  // the chain is the critical path of the whole launch (A/B: -2.5 %)
-            if (G.dbg & 8u) {  // vector-load walk, 64 chunks per wave (kept for A/B; uniform batches)
-                const uint64_t c = (uint64_t)tk * 64u + lane;
-                if (c < G.n_chunks) walk_chunk(G, c, in, in_words, chunk_word_off, wave_off, wave_words, granules, st);
-            } else if (tk < n_blockwalk) {
+            if (tk < n_blockwalk) {
                 if constexpr (kBlockWalkFits) {
                     const uint64_t c = G.uniform ? (uint64_t)tk : (uint64_t)G.walk_short[tk];
                     walk_chunk_block(G, c, in, in_words, chunk_word_off, wave_off, wave_words, granules, st, ring_all,
@@ -2287,7 +2284,7 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
             const uint32_t avail = (flw - ((~Q) >> 5)) & WMASK;
             const bool more = flw < endw;
             if (!__any(more && avail < NEED_AT)) break;
-            if (more && avail <= (uint32_t)(RW - LW) && !(G.dbg & 2u)) {
+            if (more && avail <= (uint32_t)(RW - LW) && !(kAblate && (G.dbg & 2u))) {
                 uint4 v[NV];
                 load_piece(v);
                 store_piece(v);
@@ -2303,7 +2300,7 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
         for (int i = 0; i < RW / LW; ++i) {
             if (__ballot(flw < endw && flw + (uint32_t)LW <= s0 + (uint32_t)RW) == 0) break;
             if (flw < endw && flw + (uint32_t)LW <= s0 + (uint32_t)RW) {
-                if (!(G.dbg & 2u)) { load_piece(v); store_piece(v); } else flw += (uint32_t)LW;
+                if (!(kAblate && (G.dbg & 2u))) { load_piece(v); store_piece(v); } else flw += (uint32_t)LW;
             }
         }
         wave_sync();
@@ -2329,8 +2326,15 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
         }
     };
 
-    auto decode_group = [&](auto first_tag, int tg) __attribute__((always_inline)) {
+    // Where the lane's last code ended (as Q): a valid waveform's codes end inside its last payload word, i.e.
+    // n_i = ceil(bits / 32) (src/deltaRice.c:237-241) -- checked after the last round, so that flipped payload bits
+    // that change a code length are reported (DRX_ERR_CORRUPT) instead of decoding to garbage silently.  The last
+    // step of a lane lies in an edge round or is the last step of an interior round: only those capture.
+    const uint32_t hi_step = phi + len;  // this lane decodes its last sample in step hi_step - 1
+    uint32_t Q_end = 0;
+    auto decode_group = [&](auto first_tag, auto edge_tag, int tg, uint32_t tcur) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr bool EDGE = decltype(edge_tag)::value;  // tcur + u is the step index; capture Q_end
         if (PAIR && !FIRST) {
             // two samples per ring access: a 64-bit window (three words) always holds two codes (2 x 25 bits),
             // so the second sample's window is one v_alignbit away from the first one's length -- one LDS
@@ -2342,14 +2346,18 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
                 const uint32_t lo = wp[0], hi = wp[64], lo2 = wp[-64];
                 const uint32_t winA = __builtin_amdgcn_alignbit(hi, lo, Q);
                 const uint32_t winB = __builtin_amdgcn_alignbit(lo, lo2, Q);
-                const uint32_t q1 = (uint32_t)__builtin_clz(winA);
+                const uint32_t q1 = ffbh(winA);
                 const uint32_t kk1 = (winA < (1u << 24)) ? 16u : k;
                 const uint32_t nu1 = ~(q1 + kk1);  // minus the code length
                 const uint32_t win2 = __builtin_amdgcn_alignbit(winA, winB, nu1);
-                const uint32_t q2 = (uint32_t)__builtin_clz(win2);
+                const uint32_t q2 = ffbh(win2);
                 const uint32_t kk2 = (win2 < (1u << 24)) ? 16u : k;
                 const uint32_t nu2 = ~(q2 + kk2);
                 // v_bfe_u32 and v_alignbit_b32 read 5 bits of their offset / shift: ~t == 31 - t (mod 32) serves both
+                if constexpr (EDGE) {
+                    Q_end = (tcur + (uint32_t)u + 1u == hi_step) ? Q + nu1 : Q_end;
+                    Q_end = (tcur + (uint32_t)u + 2u == hi_step) ? Q + nu1 + nu2 : Q_end;
+                }
                 asm("v_add3_u32 %0, %1, %2, %3" : "=v"(Q) : "v"(Q), "v"(nu1), "v"(nu2));
                 const uint32_t z1 = (q1 << kk1) + __builtin_amdgcn_ubfe(winA, nu1, kk1);
                 const uint32_t z2 = (q2 << kk2) + __builtin_amdgcn_ubfe(win2, nu2, kk2);
@@ -2367,7 +2375,7 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
             const uint32_t *wp = myring + row * 64u;
             const uint32_t lo = wp[0], hi = wp[64];
             const uint32_t win = __builtin_amdgcn_alignbit(hi, lo, Q);
-            const uint32_t q = (uint32_t)__builtin_clz(win);  // win == 0 only past the end of a corrupt stream
+            const uint32_t q = ffbh(win);  // win == 0 only past the end of a corrupt stream
             const bool esc = win < (1u << 24);
             const uint32_t kk = esc ? 16u : k;
             const uint32_t used = q + kk + 1u;
@@ -2386,12 +2394,13 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
                 advance(d);
                 Q -= used;
             }
+            if constexpr (EDGE) Q_end = (tcur + (uint32_t)u + 1u == hi_step) ? Q : Q_end;
             myout[tg + u] = (uint16_t)acc;
         }
     };
 
     auto write_out = [&](uint32_t t0) __attribute__((always_inline)) {
-        if (G.dbg & 1u) return;
+        if (kAblate && (G.dbg & 1u)) return;
         if (t0 >= lo_max && t0 + T <= hi_min) {  // interior round: whole aligned lines only
 #pragma unroll
             for (int i = 0; i < PPS; ++i) {
@@ -2426,7 +2435,7 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
 #pragma unroll 1
         for (int tg = 0; tg < T; tg += GS) {
             sync_refill();
-            decode_group(std::true_type{}, tg);
+            decode_group(std::true_type{}, std::true_type{}, tg, (uint32_t)tg);
         }
         wave_sync();
         write_out(0);
@@ -2446,7 +2455,7 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
 #pragma unroll 1
         for (int tg = 0; tg < T; tg += GS) {
             sync_refill();
-            decode_group(std::false_type{}, tg);
+            decode_group(std::false_type{}, std::true_type{}, tg, t0 + (uint32_t)tg);
         }
         wave_sync();
         write_out(t0);
@@ -2455,7 +2464,7 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
     uint32_t t0 = T;
     for (; t0 < steps && !(t0 >= lo_max && t0 + T <= hi_min); t0 += T) edge_round(t0);
 
-    const uint32_t min_words = (G.dbg & 4u) ? 0u : ((uint32_t)T * (k + 1u)) >> 5;
+    const uint32_t min_words = (kAblate && (G.dbg & 4u)) ? 0u : ((uint32_t)T * (k + 1u)) >> 5;
     uint4 pv0[NV], pv1[NV];               // pieces in flight
     bool pneed0 = false, pneed1 = false;  // this lane has them in flight
     set_limits();
@@ -2482,8 +2491,9 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
                 sync_refill();
                 set_limits();
             }
-            decode_group(std::false_type{}, tg);
+            decode_group(std::false_type{}, std::false_type{}, tg, 0u);
         }
+        Q_end = (t0 + (uint32_t)T == hi_step) ? Q : Q_end;  // a lane whose last step closes an interior round
         wave_sync();
         if (pneed0) store_piece(pv0);  // loads of the previous round end: older than that round's PPS stores
         if (pneed1) store_piece(pv1);
@@ -2494,12 +2504,12 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
             // samples of at least k + 1 bits each, i.e. consumed min_words more words
             const uint32_t mc = (t0 + 2u * T <= hi_min && t0 + T < steps) ? min_words : 0u;
             const uint32_t avail = (flw - ((~Q) >> 5)) & WMASK;
-            pneed0 = (flw < endw) && avail + (uint32_t)LW <= (uint32_t)RW + mc && !(G.dbg & 2u);
+            pneed0 = (flw < endw) && avail + (uint32_t)LW <= (uint32_t)RW + mc && !(kAblate && (G.dbg & 2u));
             pneed1 = pneed0 && (flw + (uint32_t)LW < endw) && avail + 2u * (uint32_t)LW <= (uint32_t)RW + mc;
             if (pneed0) load_piece(pv0);
             if (pneed1) load_piece(pv1, (uint32_t)LW);
         }
-        if (!(G.dbg & 1u)) {
+        if (!(kAblate && (G.dbg & 1u))) {
 #pragma unroll
             for (int i = 0; i < PPS; ++i) {  // whole aligned lines only
                 const int st = i * SPI + lane / PPS, p = lane % PPS;
@@ -2513,6 +2523,8 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
     if (pneed1) store_piece(pv1);
     wave_sync();
     for (; t0 < steps; t0 += T) edge_round(t0);
+    // bits of the waveform = -Q_end - 32 s0 (Q counts from A); n_i words hold them exactly
+    if (active && len && (((0u - Q_end) - 32u * s0 + 31u) >> 5) != n) atomicOr(&st->err, kErrCorrupt);
 }
 
 // ---------------------------------------------------------------------------
@@ -2671,14 +2683,9 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
     // general prediction filters: the staged kernel where it has no division to do, else the simple kernel
     const bool gen = G.n_taps != 0;
     if (gen && !G.fast_taps) impl = 0;
-    if (gen && G.fast_taps) impl = (impl == 0) ? 0 : ((impl == 1 || impl == 2 || impl == 3 || impl == 4 || impl == 7 || impl == 9 ||
-                                                       impl == 10 || impl == 11 || impl == 16) ? 7 : 8);
-    if (tables_ready && (impl == 5 || impl == 6)) impl = 1;
-    if (tables_ready && (impl == 8 || impl == 14 || impl == 15 || impl == 17)) impl = 7;
-    // the walk runs inside the decode launch; batches that need the LDS block walk (ragged ones, short
-    // waveforms) only with the 64-word ring, whose LDS the walker role borrows
-    const bool big_ring = impl == 8 || impl == 15 || impl == 5 || impl == 17;
-    const bool needs_block = !G.uniform || G.u_wave_len <= kWalkShortLen;
+    if (gen && G.fast_taps) impl = (impl == 0) ? 0 : ((impl == 1 || impl == 7) ? 7 : 8);
+    if (tables_ready && impl == 5) impl = 1;
+    if (tables_ready && impl == 8) impl = 7;
     // ragged: the group-major grid has max_groups tickets per chunk; not when most of them would be idle
     // few long waveforms (delta filter): a wavefront per waveform instead of a lane per waveform
     const bool long_path = !gen && impl != 0 && !(G.dbg & 256u) && G.uniform && long_waveform_batch(G.total_waves, G.u_wave_len);
@@ -2690,8 +2697,7 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
     const bool bw_walk = d_pw && bw_blocks_max && !tables_ready && !(G.dbg & 2048u);
     const bool rag_par = d_pw && !G.uniform && G.rag_par && !tables_ready && !(G.dbg & 2048u);
     const bool sparse = !G.uniform && (uint64_t)G.n_chunks * G.max_groups > 8ull * ((G.total_waves + 63u) / 64u) + 4096ull;
-    const bool fused = (impl == 5 || impl == 6 || impl == 8 || impl == 14 || impl == 15 || impl == 17) && (!needs_block || big_ring) &&
-                       !((G.dbg & 8u) && needs_block) && !sparse && !long_path && !par_walk && !bw_walk && !rag_par;  // the in-launch walk needs the arithmetic chunk mapping
+    const bool fused = (impl == 5 || impl == 8) && !sparse && !long_path && !par_walk && !bw_walk && !rag_par;
     if (fused) {
         // granules + ticket word, zeroed before every launch (a granule is its own ready flag)
         hipError_t e = hipMemsetAsync(d_granules, 0, (G.total_waves + 2) * sizeof(uint64_t), s);
@@ -2700,23 +2706,19 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
         uint32_t *ticket = reinterpret_cast<uint32_t *>(d_granules + G.total_waves);
         unsigned n_walk, groups;
         if (G.uniform) {
-            n_walk = (G.u_wave_len <= kWalkShortLen) ? (unsigned)G.n_chunks : blocks_for(G.n_chunks, (G.dbg & 8u) ? 64 : kWalkChains);
+            n_walk = (G.u_wave_len <= kWalkShortLen) ? (unsigned)G.n_chunks : blocks_for(G.n_chunks, kWalkChains);
             groups = (G.u_n_waves + 63u) / 64u;
         } else {
             n_walk = G.n_short + blocks_for(G.n_long, kWalkChains);
             groups = G.max_groups;
         }
         const unsigned nb = n_walk + (unsigned)(G.n_chunks * groups);
-        switch (impl) {
-            case 17: k_decode_lanes<64, 16, 64, 32, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
-            case 15: k_decode_lanes<64, 32, 64, 16, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
-            case 14: k_decode_lanes<32, 16, 64, 8, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
-            case 8:
-                if (gen) { k_decode_lanes<64, 16, 64, 16, true, true, false, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break; }
-                k_decode_lanes<64, 16, 64, 16, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
-            case 6: k_decode_lanes<32, 16, 64, 8, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
-            default: k_decode_lanes<64, 16, 64, 16, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out); break;
-        }
+        if (impl == 8 && gen)
+            k_decode_lanes<64, 16, 64, 16, true, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out);
+        else if (impl == 8)
+            k_decode_lanes<64, 16, 64, 16, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out);
+        else
+            k_decode_lanes<64, 16, 64, 16, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out);
     } else {
         // chunks of short waveforms: stream the chunk through LDS; long waveforms: one dependent load per hop
         if (tables_ready) {
@@ -2748,14 +2750,11 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                 k_walk_block_only<<<(unsigned)G.n_chunks, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_status, bw_fail);
             }
             if (impl == 5) impl = 1;
-            if (impl == 8 || impl == 14 || impl == 15 || impl == 17) impl = 7;
+            if (impl == 8) impl = 7;
         } else if (G.uniform) {
             if (G.u_wave_len <= kWalkShortLen)
                 k_walk_block<<<(unsigned)G.n_chunks, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, nullptr,
                                                                  (uint32_t)G.n_chunks, d_wave_off, d_wave_words, d_status);
-            else if (G.dbg & 8u)
-                k_walk<<<blocks_for(G.n_chunks, 64), 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off,
-                                                                 d_wave_words, d_status);
             else
                 k_walk_scalar<<<blocks_for(G.n_chunks, kWalkChains), 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off,
                                                                                  d_wave_off, d_wave_words, d_status);
@@ -2790,22 +2789,16 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
             mark(ev, 3, s);
             return hipGetLastError();
         }
-        switch (impl) {
-            case 0: k_decode_simple<<<nb, 64, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_out); break;
-            case 12: k_decode_lanes<32, 16, 64, 8, false, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
-            case 13: k_decode_lanes<64, 16, 64, 16, false, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
-            case 16: k_decode_lanes<64, 32, 64, 16, false, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
-            case 9: k_decode_lanes<32, 16, 32, 8, false, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
-            case 10: k_decode_lanes<64, 16, 32, 16, false, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
-            case 11: k_decode_lanes<32, 16, 64, 8, false, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
-            case 7:
-                if (gen) { k_decode_lanes<64, 16, 64, 16, false, true, false, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break; }
-                k_decode_lanes<64, 16, 64, 16, false, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
-            case 2: k_decode_lanes<32, 16, 64, 8, false><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
-            case 3: k_decode_lanes<32, 8, 64, 8, false><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
-            case 4: k_decode_lanes<128, 16, 64, 16, false><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
-            default: k_decode_lanes<64, 16, 64, 16, false><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out); break;
-        }
+        if (impl == 5) impl = 1;  // (a batch that cannot take the in-launch walk)
+        if (impl == 8) impl = 7;
+        if (impl == 0)
+            k_decode_simple<<<nb, 64, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_status, d_out);
+        else if (impl == 7 && gen)
+            k_decode_lanes<64, 16, 64, 16, false, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out);
+        else if (impl == 7)
+            k_decode_lanes<64, 16, 64, 16, false, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out);
+        else
+            k_decode_lanes<64, 16, 64, 16, false><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out);
     }
     mark(ev, 2, s);
     mark(ev, 3, s);

@@ -81,8 +81,12 @@ const char *drx_ctx_last_error(const drx_ctx *ctx);
 void *drx_ctx_stream(const drx_ctx *ctx);
 
 /* Plans.  chunk_wave_len[c] == 0 means "whole chunk" (WaveformLength = -1).
- * Allocates the per-waveform tables on the device; no allocation happens in
- * drx_encode / drx_decode. */
+ * Allocates the per-waveform tables and every scratch buffer the batch's geometry can need on the device;
+ * drx_encode / drx_decode allocate nothing.
+ *
+ * Threading: a context and its plans are for one thread at a time (calls are ordered on the context's stream);
+ * drx_filter_chunk_host alone takes the context's lock and may be called from any thread (HDF5 does).
+ * Every call runs on the context's device and restores the calling thread's current device before returning. */
 drx_status drx_plan_create(drx_ctx *ctx, uint64_t n_chunks, const uint32_t *chunk_samples,
                            const uint32_t *chunk_wave_len, uint32_t rice_k, drx_plan **out);
 drx_status drx_plan_create_uniform(drx_ctx *ctx, uint64_t n_chunks, uint32_t chunk_samples,
@@ -143,13 +147,14 @@ drx_status drx_plan_last_timings(drx_plan *plan, float ms[4]);
 /* Tuning / diagnostics.  Returns DRX_ERR_ARG for unknown keys or values.
  *   "profile"      1: bracket the kernels with HIP events (drx_plan_last_timings)
  *   "encode_impl"  1 (default): single pass with look-back;  0: size pass + scan + pack pass
- *   "decode_impl"  variant of the decode kernel; every one is bit-exact and covered by the parity tests:
- *        8 (default)  header walk inside the launch, 64-word ring, two samples per ring access
- *        7            the same with a separate walk kernel        5 / 1  one sample per access (fused / separate)
- *        15 / 16      128-byte stream pieces (fused / separate)   17     32-sample groups
- *        14 / 11, 6 / 2, 3   32-word ring geometries              9, 10  32-sample rounds
- *        4            128-word ring                               0      simple kernel (also: general filters)
- *   "debug_flags"  kernel ablation switches for profiling (see csrc/drx_internal.h); results may be invalid */
+ *   "decode_impl"  variant of the lane-per-waveform decode kernel; each is bit-exact and covered by the parity tests
+ *        (they exist as cross-checks of one another; measured losers of earlier rounds are in the git history):
+ *        8 (default)  header walk inside the launch, two samples per ring access     7  the same, separate walk kernel
+ *        5 / 1        one sample per ring access (fused / separate walk)             0  simple kernel (also: general filters
+ *                                                                                       the staged kernel does not take)
+ *   "debug_flags"  dispatch overrides that force an alternative (still bit-exact) path, for tests and A/B timing:
+ *        256 never the long-waveform paths, 512 long waveforms one workgroup each, 2048 never the parallel header walks,
+ *        8192 always the segment encoder.  (Ablation switches inside the kernels exist only in -DDRX_ABLATION builds.) */
 drx_status drx_ctx_set_option(drx_ctx *ctx, const char *key, int64_t value);
 
 #ifdef __cplusplus

@@ -113,7 +113,7 @@ def main():
             expect = x
             if not lossless:
                 expect = np.concatenate([O.decode_chunk(ww, opts) for ww in words])
-            for flags, impl in ((0, 8), (256, 8), (512, 8), (0, 7), (0, 1), (0, 0), (0, 14)):
+            for flags, impl in ((0, 8), (256, 8), (512, 8), (0, 7), (0, 1), (0, 0), (0, 5)):
                 ctx.set_option("debug_flags", flags)
                 ctx.set_option("decode_impl", impl)
                 log(f"  decode flags {flags} impl {impl}")

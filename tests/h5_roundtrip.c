@@ -5,6 +5,8 @@
  *   read     <file> <out.bin>                                      H5Dread through the filter
  *   chunks   <file> <prefix>                                       stored bytes of every chunk (H5Dread_chunk)
  *   writeraw <file> <rows> <cols> <chunk_rows> <M> <L> <prefix>    H5Dwrite_chunk of pre-encoded chunks
+ * Environment H5RT_CHUNK_COLS=<n>: chunks of <chunk_rows> x <n> instead of full-width rows (write; chunks then dumps
+ * the chunk grid row-major) -- /root/reference/examples/testCode.c:15-18 uses 32768 x 5 chunks of a 65536 x 10 dataset.
  */
 #include <hdf5.h>
 #include <stdio.h>
@@ -29,6 +31,7 @@ static void *slurp(const char *path, size_t *n) {
 static hid_t make_dcpl_n(hsize_t chunk_rows, hsize_t cols, size_t ncd, const unsigned *cd) {
     hid_t dcpl = H5Pcreate(H5P_DATASET_CREATE);
     hsize_t chunk[2] = {chunk_rows, cols};
+    if (getenv("H5RT_CHUNK_COLS")) chunk[1] = strtoull(getenv("H5RT_CHUNK_COLS"), 0, 10);
     H5Pset_chunk(dcpl, 2, chunk);
     if (H5Pset_filter(dcpl, FILTER, H5Z_FLAG_MANDATORY, ncd, cd) < 0) return -1;
     return dcpl;
@@ -86,8 +89,9 @@ int main(int argc, char **argv) {
         H5Sget_simple_extent_dims(space, dims, NULL);
         H5Pget_chunk(dcpl, 2, chunk);
         int idx = 0;
-        for (hsize_t r = 0; r < dims[0]; r += chunk[0], ++idx) {
-            hsize_t off[2] = {r, 0}, nbytes = 0;
+        for (hsize_t r = 0; r < dims[0]; r += chunk[0])
+        for (hsize_t c0 = 0; c0 < dims[1]; c0 += chunk[1], ++idx) {
+            hsize_t off[2] = {r, c0}, nbytes = 0;
             uint32_t mask = 0;
             CHECK(H5Dget_chunk_storage_size(dset, off, &nbytes));
             void *buf = malloc(nbytes);

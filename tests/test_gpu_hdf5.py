@@ -29,8 +29,8 @@ def h5tool(tmp_path_factory):
                     f"-I{HDF5_DIR}/include", f"-L{HDF5_DIR}/lib", "-lhdf5", f"-Wl,-rpath,{HDF5_DIR}/lib"], check=True)
     env = dict(os.environ, HDF5_PLUGIN_PATH=os.path.join(ROOT, "deltarice_amd", "plugin"))
 
-    def run(*args):
-        return subprocess.run([exe, *map(str, args)], env=env, check=True, capture_output=True, text=True)
+    def run(*args, extra_env=None):
+        return subprocess.run([exe, *map(str, args)], env=dict(env, **(extra_env or {})), check=True, capture_output=True, text=True)
     return run
 
 
@@ -105,6 +105,29 @@ def test_reference_test_suite_cases(h5tool, tmp_path, name, kind, opts):
         stored = np.fromfile(f"{tmp_path}/chunk.{c}", np.uint32)
         ref = O.encode_chunk(x.reshape(rows, cols)[c * crows:(c + 1) * crows], opts)
         assert np.array_equal(stored, ref), f"{name}: chunk {c} differs from the oracle"
+
+
+def test_reference_example_program_shape(h5tool, tmp_path):
+    """examples/testCode.c of the reference: every short value in 10 columns (65536 x 10), chunks of 32768 x 5,
+    cd_values = {8, 32768} (:15-18,32,51-53): four chunks, each the row-major bytes of a 32768 x 5 tile cut into five
+    32768-sample waveforms.  Round trip through HDF5 and stored bytes against the oracle."""
+    from oracle import oracle as O
+    rows, cols, crows, ccols = 65536, 10, 32768, 5
+    x = np.repeat(np.arange(rows, dtype=np.int64).astype(np.uint16).view(np.int16)[:, None], cols, axis=1)  # wdata[i][j] = i
+    raw, h5, back = tmp_path / "raw.bin", tmp_path / "t.h5", tmp_path / "back.bin"
+    np.ascontiguousarray(x).tofile(raw)
+    h5tool("write", h5, raw, rows, cols, crows, 8, 32768, extra_env={"H5RT_CHUNK_COLS": str(ccols)})
+    h5tool("read", h5, back)
+    assert np.array_equal(np.fromfile(back, np.int16).reshape(rows, cols), x), "Do they all match? no"
+    n = int(h5tool("chunks", h5, tmp_path / "chunk").stdout)
+    assert n == (rows // crows) * (cols // ccols)
+    idx = 0
+    for r in range(0, rows, crows):
+        for c in range(0, cols, ccols):
+            tile = np.ascontiguousarray(x[r:r + crows, c:c + ccols])
+            stored = np.fromfile(f"{tmp_path}/chunk.{idx}", np.uint32)
+            assert np.array_equal(stored, O.encode_chunk(tile, (8, 32768))), f"chunk {idx} differs from the oracle"
+            idx += 1
 
 
 def test_h5dump_sees_the_filter(h5tool, tmp_path):

@@ -82,6 +82,7 @@ struct drx_plan {
     uint64_t *d_long = nullptr;        // a handful of long waveforms: scratch of the workgroup-per-block decoder
     uint64_t *d_seg_unit_base = nullptr;  // ragged plans the segment encoder takes
     void *d_pw = nullptr;              // a handful of chunks: candidate lists of the parallel header walk
+    void *d_blk = nullptr;             // few waveforms: unit table, look-back state and flags of the block-parallel decoder
     uint32_t *d_walk_lists = nullptr;  // ragged plans: chunk indices, short-waveform chunks first
     uint32_t n_short = 0, n_long = 0;
     DevStatus *d_status = nullptr;
@@ -245,6 +246,7 @@ static void plan_free(drx_plan *p) {
     if (p->d_long) (void)hipFree(p->d_long);
     if (p->d_seg_unit_base) (void)hipFree(p->d_seg_unit_base);
     if (p->d_pw) (void)hipFree(p->d_pw);
+    if (p->d_blk) (void)hipFree(p->d_blk);
     if (p->d_status) (void)hipFree(p->d_status);
     if (p->h_status) (void)hipHostFree(p->h_status);
     for (hipEvent_t e : p->ev) if (e) (void)hipEventDestroy(e);
@@ -276,6 +278,7 @@ static drx_status plan_alloc_scratch(drx_ctx *ctx, drx_plan *p) {
     }
     if (const uint64_t nb = long_decode_scratch_bytes(p->G)) DRX_HIP(ctx, hipMalloc((void **)&p->d_long, nb));
     if (const uint64_t nb = par_walk_scratch_bytes(p->G)) DRX_HIP(ctx, hipMalloc(&p->d_pw, nb));
+    if (const uint64_t nb = blocks_scratch_bytes(p->G)) DRX_HIP(ctx, hipMalloc(&p->d_blk, nb));
     return DRX_OK;
 }
 
@@ -490,7 +493,7 @@ static drx_status decode_launch(drx_plan *p, const uint32_t *d_in, uint64_t in_w
     // not take those paths)
     DRX_HIP(ctx, launch_decode(p->G, d_in, in_words, d_chunk_word_off, d_out, p->d_wave_off,
                                p->d_wave_words, p->d_scan, p->d_status,
-                               (tables_ready ? 100 : 0) + ctx->decode_impl, p->d_long, p->d_pw,
+                               (tables_ready ? 100 : 0) + ctx->decode_impl, p->d_long, p->d_pw, p->d_blk,
                                ctx->profile ? p->ev : nullptr, ctx->stream));
     p->ev_valid = ctx->profile != 0;
     p->last_was_encode = false;

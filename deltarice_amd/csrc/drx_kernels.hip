@@ -25,109 +25,9 @@
 #include <type_traits>
 
 #include "drx_internal.h"
+#include "drx_device.h"
 
 namespace drx {
-
-// Ablation switches inside the hot loops (Geom::dbg bits 1, 2, 4, 16, 32, 64, 128) exist only in builds made with
-// -DDRX_ABLATION (loaded through DRX_LIB_PATH for A/B timing); the shipped kernels carry none of those branches.
-#ifdef DRX_ABLATION
-constexpr bool kAblate = true;
-#else
-constexpr bool kAblate = false;
-#endif
-
-// ---------------------------------------------------------------------------
-// small device helpers
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
-
-__device__ __forceinline__ void wave_sync() {
-    // All lanes of a wave run in lock step and its LDS operations complete in order;
-    // this only stops the compiler from moving LDS accesses across a phase boundary.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d);
-        if (lane >= d) v += t;
-    }
-    return v;
-}
-
-__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
-    return v;
-}
-
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        uint32_t t = __shfl_xor(v, d);
-        v = t > v ? t : v;
-    }
-    return v;
-}
-
-// Bounds on a waveform's payload word count n_i: a code has between 1 + k (q = 0, src/deltaRice.c:215-222) and 25 bits
-// (escape, :223-228).  Every walker rejects a header outside [min, max]: the chain of a valid stream never leaves them.
-__host__ __device__ __forceinline__ uint32_t max_payload_words(uint32_t len) { return (uint32_t)(((uint64_t)len * 25u + 31u) >> 5); }
-__host__ __device__ __forceinline__ uint32_t min_payload_words(uint32_t len, uint32_t k) {
-    return (uint32_t)(((uint64_t)len * (k + 1u) + 31u) >> 5);
-}
-
-// count-leading-zeros with the ISA's result for 0 (-1) instead of the source language's undefined behaviour: the
-// decoders meet an all-zero window only past the end of a corrupt stream, where any value will do, but it has to BE a value
-__device__ __forceinline__ uint32_t ffbh(uint32_t x) {
-    uint32_t r;
-    asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(x));
-    return r;
-}
-
-struct WaveRef {
-    uint64_t chunk;       // chunk index
-    uint64_t sample_off;  // first sample of this waveform in the raw batch
-    uint32_t idx;         // waveform index inside its chunk
-    uint32_t len;         // samples in this waveform
-    uint32_t n_samples;   // samples in the chunk
-};
-
-// waveform g -> chunk and extent.  Uniform batches are pure arithmetic; ragged
-// batches bisect the chunk table (once per waveform, i.e. once per ~L samples).
-__device__ __forceinline__ WaveRef locate(const Geom &G, uint64_t g) {
-    WaveRef r;
-    uint32_t L, W;
-    uint64_t c, soff;
-    if (G.uniform) {
-        c = g / G.u_n_waves;
-        r.idx = (uint32_t)(g - c * G.u_n_waves);
-        L = G.u_wave_len;
-        W = G.u_n_waves;
-        r.n_samples = G.u_n_samples;
-        soff = c * (uint64_t)G.u_n_samples;
-    } else {
-        uint64_t lo = 0, hi = G.n_chunks;  // invariant: wave_base[lo] <= g < wave_base[hi]
-        while (hi - lo > 1) {
-            uint64_t mid = (lo + hi) >> 1;
-            if (G.chunks[mid].wave_base <= g) lo = mid; else hi = mid;
-        }
-        c = lo;
-        const ChunkDesc d = G.chunks[c];
-        r.idx = (uint32_t)(g - d.wave_base);
-        L = d.wave_len;
-        W = d.n_waves;
-        r.n_samples = d.n_samples;
-        soff = d.sample_off;
-    }
-    r.chunk = c;
-    r.sample_off = soff + (uint64_t)r.idx * L;
-    r.len = (r.idx + 1 == W) ? (r.n_samples - r.idx * L) : L;  // trailing partial waveform (:420-425)
-    return r;
-}
 
 // ---------------------------------------------------------------------------
 // encode
@@ -414,17 +314,6 @@ __device__ __forceinline__ i16x2 as_i16x2(uint32_t x) { return __builtin_bit_cas
 __device__ __forceinline__ uint32_t as_u32(u16x2 x) { return __builtin_bit_cast(uint32_t, x); }
 __device__ __forceinline__ u16x2 splat(uint32_t v) { return (u16x2){(uint16_t)v, (uint16_t)v}; }
 
-// inclusive prefix sum over the 64 lanes (DPP: row shifts, then row broadcasts)
-__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
-    return v;
-}
-
 // Packed code parameters of the 8 samples a lane holds as 4 dwords (low half = earlier sample).
 //   nb   code length,
 //   c16  the code's low 16 bits: payload with the terminating '1' above it (k low bits of z | 1 << k), or the
@@ -478,7 +367,6 @@ __device__ __forceinline__ void packed_codes(const uint32_t x[4], uint32_t xprev
 }
 
 constexpr uint32_t kEncCapWords = 2048;  // LDS words per waveform buffer (8 KB): 9.3 bits/sample at L = 7000
-constexpr uint64_t kScanAgg = 1ull << 62, kScanPrefix = 2ull << 62, kScanValMask = (1ull << 62) - 1ull;
 
 // Loads this lane's 8 samples of the tile as 4 dwords; returns the number that exist.
 __device__ __forceinline__ int load8_dwords(const int16_t *__restrict__ x, uint32_t len, uint32_t t0, int lane,
@@ -581,9 +469,6 @@ __device__ __forceinline__ void place_words(const uint32_t (&wd)[4], uint32_t pe
     }
 }
 
-__device__ __forceinline__ uint32_t lds_addr(const uint32_t *p) {
-    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t *)p;
-}
 
 constexpr int kEncWaves = 8;  // waveforms (wavefronts) per workgroup = per ticket
 
@@ -1804,7 +1689,7 @@ __global__ __launch_bounds__(kLongThreads) void k_decode_long(Geom G, const uint
                                                               int16_t *__restrict__ out, uint32_t blocks_max,
                                                               const uint32_t *__restrict__ tail_end,
                                                               uint64_t *__restrict__ state, uint32_t *__restrict__ ticket,
-                                                              uint32_t *__restrict__ fail) {
+                                                              uint32_t *__restrict__ fail, const uint32_t *__restrict__ suspect = nullptr) {
     constexpr uint32_t NT = kLongThreads;
     // [kLongRows - 2 - word of the segment][thread] (a lane's bank is its lane number whatever row it reads), rows
     // in REVERSE word order plus one unused row on top: with the bit position kept negated, Q = -pos, the row
@@ -1831,7 +1716,11 @@ __global__ __launch_bounds__(kLongThreads) void k_decode_long(Geom G, const uint
         g = blockIdx.x;
     }
     if (g >= G.total_waves) return;
-    if (!MULTI && fail && !fail[g]) return;
+    if (!MULTI && fail && !fail[g]) {
+        // not flagged: the block-parallel decoder's output stands, and so does its verdict on the stream
+        if (suspect && suspect[g] && tid == 0) atomicOr(&st->err, kErrCorrupt);
+        return;
+    }
     const WaveRef r = locate(G, g);
     const uint32_t *src = in + wave_off[g] + 1;
     const uint32_t n = wave_words[g];
@@ -2673,7 +2562,7 @@ hipError_t launch_encode_long(const Geom &G, const int16_t *d_in, uint32_t *d_ou
 hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                          const uint64_t *d_chunk_word_off, int16_t *d_out, uint64_t *d_wave_off,
                          uint32_t *d_wave_words, uint64_t *d_granules, DevStatus *d_status, int impl,
-                         uint64_t *d_long, void *d_pw, hipEvent_t *ev, hipStream_t s) {
+                         uint64_t *d_long, void *d_pw, void *d_blk, hipEvent_t *ev, hipStream_t s) {
     if (G.total_waves == 0) return hipSuccess;
     mark(ev, 0, s);
     // impl >= 100: wave_off / wave_words are already filled in (the one-chunk host path walks the header
@@ -2688,7 +2577,9 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
     if (tables_ready && impl == 8) impl = 7;
     // ragged: the group-major grid has max_groups tickets per chunk; not when most of them would be idle
     // few long waveforms (delta filter): a wavefront per waveform instead of a lane per waveform
-    const bool long_path = !gen && impl != 0 && !(G.dbg & 256u) && G.uniform && long_waveform_batch(G.total_waves, G.u_wave_len);
+    const bool blocks_path = !gen && impl != 0 && !(G.dbg & (256u | 512u | 1024u)) && d_blk && blocks_batch(G);
+    // (1024: the previous generation of this path, kept for A/B: k_decode_long with a workgroup per 8192-word block)
+    const bool long_path = !blocks_path && !gen && impl != 0 && !(G.dbg & 256u) && G.uniform && long_waveform_batch(G.total_waves, G.u_wave_len);
     // a handful of chunks of long-enough waveforms: the parallel walk, then a plain decode launch
     const bool par_walk = d_pw && !tables_ready && !(G.dbg & 2048u) && G.uniform && G.n_chunks <= kPwMaxChunks &&
                           G.u_n_waves <= kPwMaxWaves && G.u_n_waves >= 64u && G.u_wave_len > kWalkShortLen;
@@ -2697,7 +2588,7 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
     const bool bw_walk = d_pw && bw_blocks_max && !tables_ready && !(G.dbg & 2048u);
     const bool rag_par = d_pw && !G.uniform && G.rag_par && !tables_ready && !(G.dbg & 2048u);
     const bool sparse = !G.uniform && (uint64_t)G.n_chunks * G.max_groups > 8ull * ((G.total_waves + 63u) / 64u) + 4096ull;
-    const bool fused = (impl == 5 || impl == 8) && !sparse && !long_path && !par_walk && !bw_walk && !rag_par;
+    const bool fused = (impl == 5 || impl == 8) && !sparse && !long_path && !blocks_path && !par_walk && !bw_walk && !rag_par;
     if (fused) {
         // granules + ticket word, zeroed before every launch (a granule is its own ready flag)
         hipError_t e = hipMemsetAsync(d_granules, 0, (G.total_waves + 2) * sizeof(uint64_t), s);
@@ -2766,6 +2657,18 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
         }
         mark(ev, 1, s);
         const unsigned nb = blocks_for(G.total_waves, 64);
+        if (blocks_path) {
+            // a workgroup per block of every waveform (drx_blocks.hip); waveforms it flags are decoded again, one
+            // workgroup each, by the kernel that also judges them
+            const uint32_t *fail = nullptr, *suspect = nullptr;
+            hipError_t e = launch_decode_blocks(G, d_in, in_words, d_wave_off, d_wave_words, d_blk, d_status, d_out, &fail, &suspect, s);
+            if (e != hipSuccess) return e;
+            k_decode_long<false><<<(unsigned)G.total_waves, kLongThreads, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_status, d_out,
+                                                                                 0u, nullptr, nullptr, nullptr, const_cast<uint32_t *>(fail), suspect);
+            mark(ev, 2, s);
+            mark(ev, 3, s);
+            return hipGetLastError();
+        }
         if (long_path) {
             const uint32_t blocks_max = long_decode_blocks_max(G);
             const uint64_t units = G.total_waves * blocks_max;

@@ -405,6 +405,44 @@ def test_short_waveform_chunks_walk_through_lds(ctx, O):
             plan.decode(dr.EncodedBatch(dev(ctx, bad.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), bad.size))
 
 
+def test_few_waveforms_take_the_block_decoder(ctx, O):
+    """Batches with too few waveforms to give each a lane are decoded a workgroup per block of each waveform's stream
+    (drx_blocks.hip): one H5Z call's worth of the README's chunk (20 x 7000), BASELINE config #1's (100 x 7000), an
+    nEDM-shaped chunk (32 x 81920), odd lengths, a leftover waveform, waveforms spanning several blocks and several
+    staging passes (zeros: 8 samples per word), every code an escape, k from 0 to 15.  Against the oracle's bytes,
+    and against the lane-per-waveform decoder (flag 256)."""
+    import deltarice_amd as dr
+    rng = np.random.default_rng(21)
+    shapes = [(1, 20, 7000, 3, "gauss10"), (3, 100, 7000, 3, "gauss10"), (2, 32, 81920, 3, "gauss10"), (1, 7, 4097, 3, "gauss300"),
+              (2, 3, 50001, 0, "zeros"), (1, 5, 30011, 3, "zeros"), (1, 4, 65536, 3, "uniform"), (2, 9, 12345, 15, "uniform"),
+              (1, 6, 20000, 1, "steps"), (1, 2, 400000, 3, "ramp"), (1, 3, 9000, 7, "gauss300"), (5, 1, 4096, 3, "gauss10")]
+    for n_chunks, W, L, k, kind in shapes:
+        N = W * L - (L // 3 if W > 2 else 0)  # a shorter last waveform where there is room for one
+        x = make_data(rng, kind, n_chunks * N)
+        if k == 0:
+            x = (x // 4).astype(np.int16)
+        opts = (1 << k, L)
+        ref_w, ref_off = O.encode_batch(x, N, opts)
+        plan = ctx.plan_uniform(n_chunks, N, opts)
+        enc = dr.EncodedBatch(dev(ctx, ref_w.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), ref_w.size)
+        for flags in (0, 256, 1024):
+            ctx.set_option("debug_flags", flags)
+            y = plan.decode(enc).cpu().numpy()
+            assert np.array_equal(y, x), (n_chunks, W, L, k, kind, flags)
+        ctx.set_option("debug_flags", 0)
+        # damage that moves code boundaries is reported, whichever block it hits
+        bad = ref_w.copy()
+        pos = int(ref_off[0]) + 2 + int(ref_w[int(ref_off[0]) + 1]) // 2
+        bad[pos:pos + 3] ^= np.uint32(0x5A5A5A5A)
+        encb = dr.EncodedBatch(dev(ctx, bad.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), bad.size)
+        try:
+            yb = plan.decode(encb).cpu().numpy()
+            assert yb.shape == x.shape  # undetectable damage (remainder bits only) decodes to other values
+        except dr.DeltaRiceError as e:
+            assert e.status == 4
+    assert np.array_equal(plan.decode(enc).cpu().numpy(), x)  # the plan is still usable
+
+
 def test_few_long_waveforms_take_the_wave_per_waveform_decoder(ctx, O):
     """WaveformLength = -1 (the reference's default: the whole chunk is one waveform) and other long waveforms are
     decoded by a wavefront each with a speculative, self-synchronising parse (k_decode_long).  Noise, a slope-1
@@ -427,9 +465,10 @@ def test_few_long_waveforms_take_the_wave_per_waveform_decoder(ctx, O):
             ref_w, ref_off = O.encode_batch(x, n, opts)
             plan = ctx.plan_uniform(3, n, (opts[0], L))
             enc = dr.EncodedBatch(dev(ctx, ref_w.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), ref_w.size)
-            # 256: lane-per-waveform decoder / single-pass encoder; 512: one workgroup per waveform;
-            # 0: the defaults for such batches (a workgroup per block, a wavefront per 8192-sample segment)
-            for flags in (256, 512, 0):
+            # 256: lane-per-waveform decoder / single-pass encoder; 512: one workgroup per waveform; 1024: the previous
+            # block decoder; 0: the defaults for such batches (a workgroup per block of the stream -- drx_blocks.hip --,
+            # a wavefront per 8192-sample segment)
+            for flags in (256, 512, 1024, 0):
                 ctx.set_option("debug_flags", flags)
                 assert np.array_equal(plan.decode(enc).cpu().numpy(), x), (name, opts, flags)
                 w, off = plan.encode(dev(ctx, x)).to_numpy()

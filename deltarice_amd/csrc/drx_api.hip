@@ -79,7 +79,6 @@ struct drx_plan {
     int32_t *d_taps = nullptr;         // general prediction filter (nullptr: delta)
     uint32_t *d_seg_bits = nullptr;    // few long waveforms: bits and bit position of every 8192-sample segment,
     uint64_t *d_seg_pos = nullptr;     // allocated by the first encode that needs them
-    uint64_t *d_long = nullptr;        // a handful of long waveforms: scratch of the workgroup-per-block decoder
     uint64_t *d_seg_unit_base = nullptr;  // ragged plans the segment encoder takes
     void *d_pw = nullptr;              // a handful of chunks: candidate lists of the parallel header walk
     void *d_blk = nullptr;             // few waveforms: unit table, look-back state and flags of the block-parallel decoder
@@ -243,7 +242,6 @@ static void plan_free(drx_plan *p) {
     if (p->d_walk_lists) (void)hipFree(p->d_walk_lists);
     if (p->d_seg_bits) (void)hipFree(p->d_seg_bits);
     if (p->d_seg_pos) (void)hipFree(p->d_seg_pos);
-    if (p->d_long) (void)hipFree(p->d_long);
     if (p->d_seg_unit_base) (void)hipFree(p->d_seg_unit_base);
     if (p->d_pw) (void)hipFree(p->d_pw);
     if (p->d_blk) (void)hipFree(p->d_blk);
@@ -276,7 +274,6 @@ static drx_status plan_alloc_scratch(drx_ctx *ctx, drx_plan *p) {
         DRX_HIP(ctx, hipMalloc((void **)&p->d_seg_bits, units * sizeof(uint32_t)));
         DRX_HIP(ctx, hipMalloc((void **)&p->d_seg_pos, units * sizeof(uint64_t)));
     }
-    if (const uint64_t nb = long_decode_scratch_bytes(p->G)) DRX_HIP(ctx, hipMalloc((void **)&p->d_long, nb));
     if (const uint64_t nb = par_walk_scratch_bytes(p->G)) DRX_HIP(ctx, hipMalloc(&p->d_pw, nb));
     if (const uint64_t nb = blocks_scratch_bytes(p->G)) DRX_HIP(ctx, hipMalloc(&p->d_blk, nb));
     return DRX_OK;
@@ -489,11 +486,11 @@ static drx_status decode_launch(drx_plan *p, const uint32_t *d_in, uint64_t in_w
     DRX_ON_DEVICE(ctx);
     DRX_HIP(ctx, hipMemsetAsync(p->d_status, 0, sizeof(DevStatus), ctx->stream));
     p->G.dbg = ctx->debug_flags;
-    // (d_long / d_pw were allocated with the plan; a plan whose filter was set to general taps afterwards simply does
+    // (d_pw / d_blk were allocated with the plan; a plan whose filter was set to general taps afterwards simply does
     // not take those paths)
     DRX_HIP(ctx, launch_decode(p->G, d_in, in_words, d_chunk_word_off, d_out, p->d_wave_off,
                                p->d_wave_words, p->d_scan, p->d_status,
-                               (tables_ready ? 100 : 0) + ctx->decode_impl, p->d_long, p->d_pw, p->d_blk,
+                               (tables_ready ? 100 : 0) + ctx->decode_impl, p->d_pw, p->d_blk,
                                ctx->profile ? p->ev : nullptr, ctx->stream));
     p->ev_valid = ctx->profile != 0;
     p->last_was_encode = false;
@@ -646,11 +643,13 @@ drx_status drx_filter_chunk_host(drx_ctx *ctx, int reverse, size_t cd_nelmts, co
             if (e != hipSuccess) { st = fail(ctx, DRX_ERR_DEVICE, "D2H failed: %s", hipGetErrorString(e)); break; }
             *out_bytes = nb;
         } else {
-            // The device finds the headers (parallel walk: 0.14 ms for one chunk).  DRX_HOST_WALK=1 walks the chain on
-            // the CPU instead while the chunk travels (0.28 ms; the faster way before the parallel walk existed) and
-            // uploads the tables.
+            // The device finds the headers of a large chunk (parallel walk: 0.14 ms for 2000 waveforms; the CPU takes 0.28 ms,
+            // DRX_HOST_WALK=1 forces that, =0 forbids it).
             const uint64_t W = plan->G.total_waves;
-            static const bool device_walk = getenv("DRX_HOST_WALK") == nullptr;
+            // A chunk of a few hundred waveforms is walked on the CPU as well: ~0.14 us per hop out of host memory against
+            // ~1 us per dependent load on the device (20 waveforms: 19 us) or the 60 us of the parallel walk's three launches.
+            static const char *walk_env = getenv("DRX_HOST_WALK");
+            const bool device_walk = walk_env ? atoi(walk_env) == 0 : W > 512u;
             const size_t tab_bytes = 16 + (device_walk ? 0 : (size_t)W * (sizeof(uint64_t) + sizeof(uint32_t)));
             if ((st = grow(ctx, &ctx->h_pin, &ctx->pin_cap, tab_bytes, true)) != DRX_OK) break;
             uint64_t *h_off = (uint64_t *)ctx->h_pin;              // [2] chunk table, then [W] wave_off

@@ -41,7 +41,8 @@ namespace drx {
 
 constexpr int kBlkSegW = 13;             // words per lane (odd)
 constexpr uint32_t kBlkPre = 8;          // words kept in front of a block: lane 0's run-up
-constexpr uint32_t kBlkGuessBits = 160;  // run-up in front of a segment (a parse is in step after a few codes)
+constexpr uint32_t kBlkGuessBits = 160;  // run-up in front of a segment (a parse is in step after a few codes; 96, 128
+                                         // and 224 bits measured: within 4 % of one another, profiles/r02_notes.md)
 constexpr uint32_t kBlkTail = 4;         // words behind a block: a code that starts inside may end 24 bits behind it,
                                          // and a window reads three words
 
@@ -49,7 +50,8 @@ template <int NT>
 struct BlkGeom {
     static constexpr uint32_t kWords = NT * kBlkSegW;                       // payload words per block
     static constexpr uint32_t kLdsWords = kBlkPre + kWords + kBlkTail + 4;  // + up to 3 words of 16-byte alignment
-    static constexpr uint32_t kOutCap = NT * 72;                            // samples staged per copy-out
+    static constexpr uint32_t kOutCap = NT * 72;                            // samples staged per copy-out (a segment holds
+                                                                            // 64 at 6.5 bits per sample; more: further passes)
     static_assert(kLdsWords % 4 == 0, "the image is filled by 16-byte pieces");
 };
 
@@ -79,10 +81,44 @@ __global__ __launch_bounds__(1024) void k_blk_units(uint64_t total_waves, const 
 
 enum { kBlkSkip = 0, kBlkCount = 1, kBlkValue = 2 };
 
-// The parse.  W: the block's LDS image (reversed words).  Qp = C - bit position.
+// count-leading-zeros that is defined for 0 (any value will do there: an all-zero window exists only in a corrupt stream)
+__device__ __forceinline__ uint32_t clz_nz(uint32_t x) { return (uint32_t)__builtin_clz(x | 1u); }
+
+// Two codes from the 64-bit window at Qp (three words: a 64-bit window always holds two codes of at most 25 bits).
+// W: the block's LDS image; word w of the image sits at W[K + 1 - w] and Qp = 32 K - (bit position), so that
+// W[Qp >> 5 .. + 2] are the window's words, last one first, and v_alignbit(hi, lo, Qp) is its first half -- also on a
+// word boundary (as in k_decode_lanes).  nu = minus the code length; v_bfe_u32 / v_alignbit_b32 read 5 bits of their
+// offset / shift, ~t == 31 - t (mod 32) serves both.
+struct BlkPair { uint32_t nu1, nu2, z1, z2; };
+template <bool VALUES>
+__device__ __forceinline__ BlkPair blk_pair(const uint32_t *W, uint32_t k, uint32_t Qp) {
+    const uint32_t idx = Qp >> 5;
+    const uint32_t lo2 = W[idx], lo = W[idx + 1u], hi = W[idx + 2u];
+    const uint32_t winA = __builtin_amdgcn_alignbit(hi, lo, Qp);
+    const uint32_t winB = __builtin_amdgcn_alignbit(lo, lo2, Qp);
+    const uint32_t q1 = clz_nz(winA);
+    const uint32_t kk1 = (winA < (1u << 24)) ? 16u : k;  // escape: eight zeros (:223-228)
+    BlkPair r;
+    r.nu1 = ~(q1 + kk1);
+    const uint32_t win2 = __builtin_amdgcn_alignbit(winA, winB, r.nu1);
+    const uint32_t q2 = clz_nz(win2);
+    const uint32_t kk2 = (win2 < (1u << 24)) ? 16u : k;
+    r.nu2 = ~(q2 + kk2);
+    r.z1 = r.z2 = 0;
+    if (VALUES) {
+        r.z1 = (q1 << kk1) + __builtin_amdgcn_ubfe(winA, r.nu1, kk1);
+        r.z2 = (q2 << kk2) + __builtin_amdgcn_ubfe(win2, r.nu2, kk2);
+    }
+    return r;
+}
+__device__ __forceinline__ uint32_t unzigzag(uint32_t z) { return (z >> 1) ^ (0u - (z & 1u)); }  // :172-177
+
+// The parse.
 //   kBlkSkip / kBlkCount: codes are taken while they START before the limit (Qp > qlim);
-//   kBlkValue: exactly `cmax` codes (c counts them), each running sum stored as int16 at outp[c].
-// Two codes per LDS access: a 64-bit window (three words) always holds two codes of at most 25 bits.
+//   kBlkValue: exactly `cmax` codes (c counts them), each running sum (:80-89) stored as int16 at outp[c].
+// A lane that is not enabled keeps its state.  (A variant that ran a wave without per-code masks while every lane had
+// room for two more codes, and only the last few codes masked, was measured 4-8 % SLOWER: the vote per pair and the
+// second loop cost what the masks had: profiles/r02_notes.md.)
 template <int MODE>
 __device__ __forceinline__ void blk_parse(const uint32_t *W, uint32_t k, bool enable, uint32_t &Qp, uint32_t qlim,
                                           uint32_t &c, uint32_t &sum, uint32_t cmax, uint16_t *outp) {
@@ -92,26 +128,13 @@ __device__ __forceinline__ void blk_parse(const uint32_t *W, uint32_t k, bool en
     while (__any(more(Qp, c))) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {  // one vote per four codes
-            const uint32_t idx = Qp >> 5;
-            const uint32_t lo2 = W[idx - 1u], lo = W[idx], hi = W[idx + 1u];
-            const uint32_t winA = __builtin_amdgcn_alignbit(hi, lo, Qp);
-            const uint32_t winB = __builtin_amdgcn_alignbit(lo, lo2, Qp);
-            const uint32_t q1 = ffbh(winA);
-            const uint32_t kk1 = (winA < (1u << 24)) ? 16u : k;  // escape: eight zeros (:223-228)
-            const uint32_t nu1 = ~(q1 + kk1);                     // minus the code length
-            const uint32_t win2 = __builtin_amdgcn_alignbit(winA, winB, nu1);
-            const uint32_t q2 = ffbh(win2);
-            const uint32_t kk2 = (win2 < (1u << 24)) ? 16u : k;
-            const uint32_t nu2 = ~(q2 + kk2);
+            const BlkPair p = blk_pair<MODE != kBlkSkip>(W, k, Qp);
             const bool act1 = more(Qp, c);
-            const uint32_t Qa = Qp + nu1;
+            const uint32_t Qa = Qp + p.nu1;
             const bool act2 = act1 && more(Qa, c + 1u);
             if (MODE != kBlkSkip) {
-                // v_bfe_u32 reads 5 bits of its offset: ~t == 31 - t (mod 32)
-                const uint32_t z1 = (q1 << kk1) + __builtin_amdgcn_ubfe(winA, nu1, kk1);
-                const uint32_t z2 = (q2 << kk2) + __builtin_amdgcn_ubfe(win2, nu2, kk2);
-                const uint32_t s1 = sum + ((z1 >> 1) ^ (0u - (z1 & 1u)));  // un-zig-zag (:172-177), running sum (:80-89)
-                const uint32_t s2 = s1 + ((z2 >> 1) ^ (0u - (z2 & 1u)));
+                const uint32_t s1 = sum + unzigzag(p.z1);
+                const uint32_t s2 = s1 + unzigzag(p.z2);
                 if (MODE == kBlkValue) {
                     if (act1) outp[c] = (uint16_t)s1;
                     if (act2) outp[c + 1u] = (uint16_t)s2;
@@ -119,7 +142,7 @@ __device__ __forceinline__ void blk_parse(const uint32_t *W, uint32_t k, bool en
                 sum = act2 ? s2 : (act1 ? s1 : sum);
             }
             c += (act1 ? 1u : 0u) + (act2 ? 1u : 0u);
-            Qp = act2 ? Qa + nu2 : (act1 ? Qa : Qp);
+            Qp = act2 ? Qa + p.nu2 : (act1 ? Qa : Qp);
         }
     }
 }
@@ -133,16 +156,19 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
                                                       uint32_t *__restrict__ fail, uint32_t *__restrict__ suspect,
                                                       DevStatus *st, int16_t *__restrict__ out) {
     using BG = BlkGeom<NT>;
-    constexpr uint32_t RT = BG::kLdsWords + 3u;  // word w of the image sits at W[RT - w]
-    constexpr uint32_t C = 32u * RT;
+    constexpr uint32_t K = BG::kLdsWords + 2u;  // word w of the image sits at W[K + 1 - w]; K = 2 (mod 4): 16-byte quads
+    constexpr uint32_t C = 32u * K;
     constexpr int NW = NT / 64;
     constexpr uint32_t kSegBits = 32u * kBlkSegW;
-    __shared__ __attribute__((aligned(16))) uint32_t W[BG::kLdsWords + 8];
-    __shared__ __attribute__((aligned(16))) uint16_t obuf[BG::kOutCap + 16];
-    __shared__ uint32_t s_e[NT];
-    __shared__ uint32_t s_tot[2][NW];
-    __shared__ uint64_t s_b[2];
-    __shared__ uint32_t s_unit, s_pred;
+    // one LDS object, the image first: its three-word windows are read with immediate offsets from address 0
+    constexpr uint32_t kWSize = BG::kLdsWords + 4u, kObufWords = (BG::kOutCap + 16u) / 2u;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kWSize + kObufWords + NT + 2 * NW + 4 + 2];
+    uint32_t *const W = lds;
+    uint16_t *const obuf = reinterpret_cast<uint16_t *>(lds + kWSize);
+    uint32_t *const s_e = lds + kWSize + kObufWords;
+    uint32_t(*const s_tot)[NW] = reinterpret_cast<uint32_t(*)[NW]>(s_e + NT);
+    uint64_t *const s_b = reinterpret_cast<uint64_t *>(s_e + NT + 2 * NW);  // (kWSize, kObufWords, NT, 2 NW: all even)
+    uint32_t &s_unit = s_e[NT + 2 * NW + 4], &s_pred = s_e[NT + 2 * NW + 5];
     const uint32_t tid = threadIdx.x;
     const int lane = lane_id(), wv = (int)(tid >> 6);
     const uint32_t k = G.k;
@@ -189,7 +215,7 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
                 auto ld = [&](int64_t i) { return (i >= 0 && i < (int64_t)in_words && i < pay_hi) ? in[i] : 0u; };
                 v = make_uint4(ld(a), ld(a + 1), ld(a + 2), ld(a + 3));
             }
-            // words 4q .. 4q+3 at W[RT - 4q - 3 .. RT - 4q]: one 16-byte store (RT - 4q - 3 = kLdsWords - 4q)
+            // words 4q .. 4q+3 at W[K - 4q - 2 .. K - 4q + 1]: one 16-byte store (K - 4q - 2 = kLdsWords - 4q)
             *reinterpret_cast<uint4 *>(W + (BG::kLdsWords - 4u * q)) = make_uint4(v.w, v.z, v.y, v.x);
         }
         __syncthreads();
@@ -200,11 +226,13 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
         const bool active = bj < bend;
         const uint32_t lim = (bj + kSegBits < bend) ? bj + kSegBits : bend;
         const bool exact0 = tid == 0 && blk == 0;  // the waveform's first code starts at bit 0
-        uint32_t Qp = C - (exact0 ? B0 : bj - kBlkGuessBits);
+        uint32_t Qp = C - ((exact0 || !active) ? B0 : bj - kBlkGuessBits);
         uint32_t cnt = 0, sum = 0, dummy_c = 0, dummy_s = 0;
         blk_parse<kBlkSkip>(W, k, active && !exact0, Qp, C - bj, dummy_c, dummy_s, 0u, nullptr);
+        if (exact0 || !active) Qp = C - B0;
         uint32_t f = C - Qp;  // first code that starts in my segment
         blk_parse<kBlkCount>(W, k, active, Qp, C - lim, cnt, sum, 0u, nullptr);
+        if (!active) { cnt = 0; sum = 0; }
         uint32_t e = C - Qp;  // first code that starts behind it
 
         // every lane must start where its predecessor ended; lanes that do not, start again from there
@@ -310,7 +338,7 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
 
         // ---- phase 2: the samples, staged in output order, whole lines to HBM ----
         uint32_t c = 0, acc = acc_base + pre_s + incl_s - sum;
-        Qp = C - f;
+        Qp = C - (todo ? f : B0);
         const uint32_t a0 = (uint32_t)((((uintptr_t)(y + blk_first)) >> 1) & 7u);  // kOutCap is a multiple of 8: the same every pass
         for (uint32_t R0 = 0; R0 < blk_count; R0 += BG::kOutCap) {
             // my samples with block-relative index below R0 + kOutCap
@@ -336,7 +364,7 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
             __syncthreads();
         }
         // the waveform's last code must end in its last payload word: n_i = ceil(bits / 32) (src/deltaRice.c:237-241)
-        if (todo && (uint64_t)blk_first + rel0 + todo == (uint64_t)len) {
+        if (todo && c == todo && (uint64_t)blk_first + rel0 + todo == (uint64_t)len) {
             const uint32_t bits_in_block = (C - Qp) - B0;
             if (w0 + ((bits_in_block + 31u) >> 5) != n) atomicExch(suspect + g, 1u);
         }
@@ -347,16 +375,19 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-// Which batches take this decoder: uniform, delta filter, too few waveforms to give each a lane of a full chip
-// (98 304 lanes), waveforms long enough to give a block's lanes something to do.
+// Which batches take this decoder: uniform, delta filter, and fewer waveforms than a quarter of the lanes of the chip.
+// Measured crossover against k_decode_lanes (tools/len_sweep.py, profiles/r02_blocks_vs_lanes.txt): a lane decodes
+// ~17 samples per microsecond whatever else runs, so the lane kernel takes ~60 ns x WaveformLength until the chip is
+// full (98 304 lanes); this kernel decodes ~400 samples per nanosecond once it has a few hundred blocks: the two
+// meet near 24 000 waveforms for every WaveformLength from 4096 to 65 536.
 bool blocks_batch(const Geom &G) {
-    return G.uniform && G.n_taps == 0 && G.total_waves <= 49152u && G.u_wave_len >= 4096u;
+    return G.uniform && G.n_taps == 0 && G.total_waves <= 24576u && G.u_wave_len >= 2048u;
 }
 
 static int blocks_nt(const Geom &G) {
-    // a waveform of about (k + 3.5) bits per sample that fits 128 lanes' segments wastes half of 256
+    // lanes per block: a waveform of about (k + 3.5) bits per sample should fill most of its last block
     const uint64_t typ_words = ((uint64_t)G.u_wave_len * (2u * G.k + 7u)) >> 6;
-    return typ_words <= blk_words(128) ? 128 : 256;
+    return typ_words <= blk_words(64) ? 64 : (typ_words <= blk_words(128) ? 128 : 256);
 }
 
 static uint64_t blocks_units_max(const Geom &G) {
@@ -397,9 +428,13 @@ hipError_t launch_decode_blocks(const Geom &G, const uint32_t *d_in, uint64_t in
     if (e != hipSuccess) return e;
     const int nt = blocks_nt(G);
     k_blk_units<<<1, 1024, 0, s>>>(G.total_waves, d_wave_words, blk_words((uint32_t)nt), L.unit_first);
-    // resident grid: 256 CUs x workgroups per CU (LDS: 51 KB at NT = 256, 26 KB at NT = 128), never more than there are units
+    // resident grid: 256 CUs x workgroups per CU (LDS: 51 KB at NT = 256, 26 KB at 128, 13 KB at 64), never more than there are units
     const uint64_t units = blocks_units_max(G);
-    if (nt == 128) {
+    if (nt == 64) {
+        const unsigned grid = (unsigned)(units < 256u * 12u ? units : 256u * 12u);
+        k_decode_blocks<64><<<grid, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, L.unit_first, L.state, L.ends, L.ticket,
+                                               L.fail, L.suspect, d_status, d_out);
+    } else if (nt == 128) {
         const unsigned grid = (unsigned)(units < 256u * 6u ? units : 256u * 6u);
         k_decode_blocks<128><<<grid, 128, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, L.unit_first, L.state, L.ends, L.ticket,
                                                  L.fail, L.suspect, d_status, d_out);

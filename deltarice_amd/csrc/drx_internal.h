@@ -90,7 +90,7 @@ hipError_t launch_encode_long(const Geom &G, const int16_t *d_in, uint32_t *d_ou
 hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                          const uint64_t *d_chunk_word_off, int16_t *d_out, uint64_t *d_wave_off,
                          uint32_t *d_wave_words, uint64_t *d_granules, DevStatus *d_status, int impl,
-                         uint64_t *d_long, void *d_pw, void *d_blk, hipEvent_t *ev, hipStream_t s);
+                         void *d_pw, void *d_blk, hipEvent_t *ev, hipStream_t s);
 // block-parallel decoder for batches of few waveforms (drx_blocks.hip): a workgroup per block of a waveform's stream
 bool blocks_batch(const Geom &G);
 uint64_t blocks_scratch_bytes(const Geom &G);
@@ -99,8 +99,6 @@ hipError_t launch_decode_blocks(const Geom &G, const uint32_t *d_in, uint64_t in
                                 const uint32_t **fail_out, const uint32_t **suspect_out, hipStream_t s);
 uint64_t par_walk_scratch_bytes(const Geom &G);
 uint32_t bw_walk_blocks_max(const Geom &G);
-// scratch of the workgroup-per-block decoder of a handful of long waveforms (0: that path is not taken)
-uint64_t long_decode_scratch_bytes(const Geom &G);
 constexpr uint32_t kWalkShortLenHost = 2048;  // keep equal to kWalkShortLen in drx_kernels.hip
 // WaveformLengths the segment encoder takes in any batch: up to kSegShortLenHost, and from kSegLongLenHost
 constexpr uint32_t kSegShortLenHost = 3072, kSegLongLenHost = 10240;

@@ -1671,25 +1671,19 @@ __host__ __device__ inline bool long_waveform_batch(uint64_t total_waves, uint32
 
 constexpr int kLongWaves = 8;                 // wavefronts per workgroup
 constexpr int kLongThreads = 64 * kLongWaves;  // segments parsed at once
-constexpr uint32_t kLongBlockWords = kLongThreads * kLongSeg;  // 8192 words of the stream per block
 constexpr uint32_t kLongGuessBits = 160;  // bits in front of a segment's end from which the first guess is parsed
 
-// MULTI = false: one workgroup per waveform walks its blocks in order (fail != nullptr: only the waveforms it flags).
-// MULTI = true (a handful of waveforms: one workgroup each would leave the GPU empty): one workgroup per BLOCK.
-//   The bit at which a block's first code starts is predicted by k_long_tail (a parse of the previous block's
-//   last 64 words from an assumed boundary: it has re-synchronised by the block's end, or the check below fails),
-//   the number of samples and the delta sum in front of a block come from a decoupled look-back over the
-//   blocks of the waveform (tickets, 8-byte {status | count | sum} entries, as in the encoder).  A block whose
-//   real end differs from the prediction its successor used flags the waveform; flagged waveforms are decoded
-//   again by the MULTI = false kernel afterwards.
-template <bool MULTI>
+// One workgroup per waveform walks its blocks in order (fail != nullptr: only the waveforms it flags).  This is the
+// FALLBACK of the block-parallel decoder (drx_blocks.hip), which gives every block a workgroup of its own and is 2-6 x
+// faster where a parse falls into step within a few codes; waveforms where that fails (a slope-1 ramp: all codes the same
+// length) are flagged and come here, where a block starts exactly where its predecessor ended.  (The workgroup-per-block
+// form of THIS kernel, with a tail parse predicting block starts, was round 1's path for a handful of long waveforms; the
+// new decoder replaced it: 25 x 14 M samples 1.55 -> 0.83 ms, profiles/r02_notes.md.)
 __global__ __launch_bounds__(kLongThreads) void k_decode_long(Geom G, const uint32_t *__restrict__ in,
                                                               const uint64_t *__restrict__ wave_off,
                                                               const uint32_t *__restrict__ wave_words, DevStatus *st,
-                                                              int16_t *__restrict__ out, uint32_t blocks_max,
-                                                              const uint32_t *__restrict__ tail_end,
-                                                              uint64_t *__restrict__ state, uint32_t *__restrict__ ticket,
-                                                              uint32_t *__restrict__ fail, const uint32_t *__restrict__ suspect = nullptr) {
+                                                              int16_t *__restrict__ out, const uint32_t *__restrict__ fail,
+                                                              const uint32_t *__restrict__ suspect) {
     constexpr uint32_t NT = kLongThreads;
     // [kLongRows - 2 - word of the segment][thread] (a lane's bank is its lane number whatever row it reads), rows
     // in REVERSE word order plus one unused row on top: with the bit position kept negated, Q = -pos, the row
@@ -1700,23 +1694,11 @@ __global__ __launch_bounds__(kLongThreads) void k_decode_long(Geom G, const uint
     __shared__ uint32_t col[kLongRows * NT];
     __shared__ uint32_t s_end[NT];
     __shared__ uint32_t s_tot[2][kLongWaves];
-    __shared__ uint64_t s_bcast[2];
     const uint32_t tid = threadIdx.x;
     const int wv = (int)(tid >> 6), lane = (int)(tid & 63u);
-    uint64_t g, unit = 0;
-    uint32_t blk = 0;
-    if (MULTI) {
-        if (tid == 0) s_bcast[0] = atomicAdd(ticket, 1u);
-        __syncthreads();
-        unit = s_bcast[0];
-        __syncthreads();
-        g = unit / blocks_max;
-        blk = (uint32_t)(unit - g * blocks_max);
-    } else {
-        g = blockIdx.x;
-    }
+    const uint64_t g = blockIdx.x;
     if (g >= G.total_waves) return;
-    if (!MULTI && fail && !fail[g]) {
+    if (fail && !fail[g]) {
         // not flagged: the block-parallel decoder's output stands, and so does its verdict on the stream
         if (suspect && suspect[g] && tid == 0) atomicOr(&st->err, kErrCorrupt);
         return;
@@ -1726,11 +1708,8 @@ __global__ __launch_bounds__(kLongThreads) void k_decode_long(Geom G, const uint
     const uint32_t n = wave_words[g];
     int16_t *y = out + r.sample_off;
     const uint32_t len = r.len, k = G.k;
-    const uint32_t n_blocks = (n + kLongBlockWords - 1u) / kLongBlockWords;
-    if (MULTI && blk >= n_blocks) return;
-
-    uint32_t blk_word = MULTI ? blk * kLongBlockWords : 0u;  // first word of the block
-    uint32_t carry_in = (MULTI && blk) ? tail_end[unit - 1u] : 0u;  // bit of thread 0's segment at which the next code starts
+    uint32_t blk_word = 0;  // first word of the block
+    uint32_t carry_in = 0;  // bit of thread 0's segment at which the next code starts
     uint32_t done = 0;      // samples written
     uint32_t acc_base = 0;  // running sum before the block (mod 2^16)
 
@@ -1743,16 +1722,9 @@ __global__ __launch_bounds__(kLongThreads) void k_decode_long(Geom G, const uint
         uint32_t Q = 0u - start;  // minus the bit position
         const uint32_t lim = avail_bits < kLongSegBits ? avail_bits : kLongSegBits;
         const int32_t nlim = enable ? -(int32_t)lim : 1;  // a code is taken while -Q < lim, i.e. Q > -lim
-        // EMIT: four samples per store where they fill an aligned 8 bytes (2-byte stores run into the L2's request
-        // rate: 350 M of them in 2 ms; ablation: the stores were a third of the kernel).  q4: the last four samples,
-        // newest on top; nh: how many of them have not been stored yet; last_i: index of the newest one.
-        // (MULTI, one block per workgroup: quads, -12 %; a workgroup that walks its waveform block by block did better
-        // with pairs -- 65 536-sample waveforms 1.9 ms against 2.1 ms -- so it keeps them: QUADS below)
-        constexpr bool QUADS = MULTI;
-        const uint32_t par4 = (uint32_t)(((uintptr_t)y >> 1) & 3u);  // sample 0's slot in its aligned quad (pairs: & 1)
-        uint64_t q4 = 0;
-        uint32_t nh = 0, last_i = 0;   // QUADS
-        uint32_t held = 0, held_i = 0;  // pairs: the sample waiting for its partner
+        // EMIT: two samples per store where they fill an aligned dword (2-byte stores run into the L2's request rate)
+        const uint32_t par4 = (uint32_t)(((uintptr_t)y >> 1) & 1u);  // sample 0's half of its aligned dword
+        uint32_t held = 0, held_i = 0;  // the sample waiting for its partner
         bool holding = false;
         // LDS byte address of this thread's row of word 0
         const uint32_t row0 = lds_addr(col) + ((kLongRows - 2u) * NT + tid) * 4u;
@@ -1773,29 +1745,15 @@ __global__ __launch_bounds__(kLongThreads) void k_decode_long(Geom G, const uint
                 if (EMIT) {
                     if (act && idx + c < len && !(kAblate && (G.dbg & 16384u))) {  // (16384: ablation, no stores)
                         const uint32_t i = idx + c;
-                        if constexpr (QUADS) {
-                            q4 = (q4 >> 16) | ((uint64_t)(s2 & 0xffffu) << 48);
-                            ++nh;
-                            last_i = i;
-                            if (((i + par4) & 3u) == 3u) {  // the quad is complete
-                                if (nh == 4u) {
-                                    *reinterpret_cast<uint64_t *>(y + i - 3u) = q4;
-                                } else {  // the lane started inside this quad
-                                    for (uint32_t j = 0; j < nh; ++j) y[i - j] = (int16_t)(uint16_t)(q4 >> (48u - 16u * j));
-                                }
-                                nh = 0;
-                            }
+                        if (((i + par4) & 1u) == 0u) {  // low half of an aligned dword: wait for the next sample
+                            held = s2 & 0xffffu;
+                            held_i = i;
+                            holding = true;
+                        } else if (holding) {
+                            *reinterpret_cast<uint32_t *>(y + i - 1u) = held | (s2 << 16);
+                            holding = false;
                         } else {
-                            if (((i + par4) & 1u) == 0u) {  // low half of an aligned dword: wait for the next sample
-                                held = s2 & 0xffffu;
-                                held_i = i;
-                                holding = true;
-                            } else if (holding) {
-                                *reinterpret_cast<uint32_t *>(y + i - 1u) = held | (s2 << 16);
-                                holding = false;
-                            } else {
-                                y[i] = (int16_t)(uint16_t)s2;  // the lane's first sample sits in a high half
-                            }
+                            y[i] = (int16_t)(uint16_t)s2;  // the lane's first sample sits in a high half
                         }
                     }
                 }
@@ -1804,10 +1762,7 @@ __global__ __launch_bounds__(kLongThreads) void k_decode_long(Geom G, const uint
                 c += act ? 1u : 0u;
             }
         }
-        if (EMIT) {  // the lane's last samples did not fill a quad / the last sample had no partner
-            if (QUADS) { for (uint32_t j = 0; j < nh; ++j) y[last_i - j] = (int16_t)(uint16_t)(q4 >> (48u - 16u * j)); }
-            else if (holding) y[held_i] = (int16_t)(uint16_t)held;
-        }
+        if (EMIT && holding) y[held_i] = (int16_t)(uint16_t)held;  // the lane's last sample had no partner
         const uint32_t pos = 0u - Q;
         end = pos;
         cnt = c;
@@ -1863,91 +1818,15 @@ __global__ __launch_bounds__(kLongThreads) void k_decode_long(Geom G, const uint
             tot_s += ts;
         }
         const uint32_t end_last = s_end[NT - 1u];
-        if (MULTI) {
-            // samples / delta sum in front of this block: look back over the blocks of the waveform
-            if (wv == 0) {
-                const uint64_t mine = ((uint64_t)tot_c << 16) | (uint64_t)(tot_s & 0xffffu);
-                uint64_t ex_c = 0, ex_s = 0;
-                if (blk == 0) {
-                    if (lane == 0) __hip_atomic_store(state + unit, kScanPrefix | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else {
-                    if (lane == 0) __hip_atomic_store(state + unit, kScanAgg | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const int64_t first = (int64_t)(unit - blk);  // block 0 of this waveform
-                    int64_t base = (int64_t)unit - 1;
-                    uint32_t spins = 0;
-                    for (;;) {
-                        const int64_t i0 = base - lane;
-                        uint64_t sv = kScanPrefix;  // in front of block 0: an empty prefix
-                        if (i0 >= first) sv = __hip_atomic_load(state + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const uint32_t stt = (uint32_t)(sv >> 62);
-                        const uint64_t pm = __ballot(stt == 2u), zm = __ballot(stt == 0u);
-                        const int fp = pm ? __builtin_ctzll(pm) : 64;
-                        const uint64_t nearer = fp >= 64 ? ~0ull : ((1ull << fp) - 1ull);
-                        if (zm & nearer) {
-                            __builtin_amdgcn_s_sleep(1);
-                            if (++spins > (1u << 22)) { if (lane == 0) atomicOr(&st->err, kErrInternal); break; }
-                            continue;
-                        }
-                        const uint64_t val = (lane <= fp) ? (sv & kScanValMask) : 0ull;
-                        ex_c += wave_sum_u64(val >> 16);
-                        ex_s += wave_sum_u64(val & 0xffffull);
-                        if (fp < 64) break;
-                        base -= 64;
-                    }
-                    if (lane == 0)
-                        __hip_atomic_store(state + unit, kScanPrefix | ((((ex_c + tot_c) << 16) | ((ex_s + tot_s) & 0xffffull)) & kScanValMask),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                if (lane == 0) { s_bcast[0] = ex_c; s_bcast[1] = ex_s; }
-            }
-            __syncthreads();
-            done = (uint32_t)(s_bcast[0] > (uint64_t)len ? (uint64_t)len : s_bcast[0]);
-            acc_base = (uint32_t)s_bcast[1];
-            // the successor started from the predicted end of this block
-            if (tid == 0 && blk + 1u < n_blocks) {
-                const uint32_t real = end_last >= kLongSegBits ? end_last - kLongSegBits : 0u;
-                if (real != tail_end[unit]) atomicExch(fail + g, 1u);
-            }
-        }
         uint32_t e3, c3, s3;
         parse(true, start, avail_bits, std::true_type{}, done + pre_c + incl_c - cnt, acc_base + pre_s + incl_s - sum, e3, c3, s3);
         done = (tot_c > len - done) ? len : done + tot_c;
-        if (MULTI) {
-            // too few samples: a wrong prediction somewhere in front, or a stream that really ends early -- the
-            // one-workgroup kernel decides (it decodes flagged waveforms again and is the one that raises kErrCorrupt)
-            if (blk + 1u == n_blocks && done < len && tid == 0) atomicExch(fail + g, 1u);
-            return;
-        }
         acc_base += tot_s;
         carry_in = end_last >= kLongSegBits ? end_last - kLongSegBits : 0u;
         blk_word += NT * kLongSeg;
         __syncthreads();
     }
-    if (!MULTI && done < len && tid == 0) atomicOr(&st->err, kErrCorrupt);  // the stream ended before the waveform did
-}
-
-// MULTI: where block b + 1's first code starts, predicted by one lane per block from the last 64 words of block b
-__global__ __launch_bounds__(64) void k_long_tail(Geom G, const uint32_t *__restrict__ in, const uint64_t *__restrict__ wave_off,
-                                                  const uint32_t *__restrict__ wave_words, uint32_t blocks_max,
-                                                  uint32_t *__restrict__ tail_end) {
-    const uint64_t unit = (uint64_t)blockIdx.x * 64u + threadIdx.x;
-    const uint64_t g = unit / blocks_max;
-    if (g >= G.total_waves) return;
-    const uint32_t blk = (uint32_t)(unit - g * blocks_max);
-    const uint32_t n = wave_words[g];
-    const uint32_t n_blocks = (n + kLongBlockWords - 1u) / kLongBlockWords;
-    if (blk + 1u >= n_blocks) return;  // the last block has no successor
-    const uint32_t *src = in + wave_off[g] + 1;
-    const uint32_t w0 = (blk + 1u) * kLongBlockWords - 64u, k = G.k;
-    uint32_t pos = 0;
-    while (pos < 64u * 32u) {
-        const uint32_t w = w0 + (pos >> 5);
-        const uint64_t two = ((uint64_t)(w < n ? src[w] : 0u) << 32) | (w + 1u < n ? src[w + 1u] : 0u);
-        const uint32_t win = (uint32_t)((two << (pos & 31u)) >> 32);
-        const uint32_t q = win ? (uint32_t)__builtin_clz(win) : 32u;
-        pos += q + ((win < (1u << 24)) ? 16u : k) + 1u;
-    }
-    tail_end[unit] = pos - 64u * 32u;
+    if (done < len && tid == 0) atomicOr(&st->err, kErrCorrupt);  // the stream ended before the waveform did
 }
 
 // Staged lane-per-waveform decoder (the production kernel; generations 1-4 are in the git
@@ -2473,18 +2352,6 @@ hipError_t launch_encode(const Geom &G, const int16_t *d_in, uint32_t *d_out, ui
     return hipGetLastError();
 }
 
-// workgroup-per-block decode of a handful of long waveforms
-constexpr uint64_t kLongMultiMaxWaves = 256;
-uint32_t long_decode_blocks_max(const Geom &G) {  // 25 bits per sample at worst
-    const uint64_t max_words = ((uint64_t)G.u_wave_len * 25u + 31u) >> 5;
-    return (uint32_t)((max_words + kLongBlockWords - 1u) / kLongBlockWords);
-}
-uint64_t long_decode_scratch_bytes(const Geom &G) {
-    if (!(G.uniform && G.n_taps == 0 && long_waveform_batch(G.total_waves, G.u_wave_len)) || G.total_waves > kLongMultiMaxWaves) return 0;
-    const uint64_t units = G.total_waves * long_decode_blocks_max(G);
-    return units * 12u + (G.total_waves + 2u) * 4u;
-}
-
 // Batches the segment encoder takes: few long waveforms, and SHORT waveforms (one segment each), where the
 // single-pass encoder pays a workgroup barrier, a look-back and an 8 KB LDS clear per 512-2048 samples
 // (200 chunks of 14 M samples: L = 512 0.57 -> 0.95 TB/s, 1024 0.97 -> 1.33, 2048 1.51 -> 1.68), and waveforms
@@ -2562,7 +2429,7 @@ hipError_t launch_encode_long(const Geom &G, const int16_t *d_in, uint32_t *d_ou
 hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                          const uint64_t *d_chunk_word_off, int16_t *d_out, uint64_t *d_wave_off,
                          uint32_t *d_wave_words, uint64_t *d_granules, DevStatus *d_status, int impl,
-                         uint64_t *d_long, void *d_pw, void *d_blk, hipEvent_t *ev, hipStream_t s) {
+                         void *d_pw, void *d_blk, hipEvent_t *ev, hipStream_t s) {
     if (G.total_waves == 0) return hipSuccess;
     mark(ev, 0, s);
     // impl >= 100: wave_off / wave_words are already filled in (the one-chunk host path walks the header
@@ -2577,8 +2444,7 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
     if (tables_ready && impl == 8) impl = 7;
     // ragged: the group-major grid has max_groups tickets per chunk; not when most of them would be idle
     // few long waveforms (delta filter): a wavefront per waveform instead of a lane per waveform
-    const bool blocks_path = !gen && impl != 0 && !(G.dbg & (256u | 512u | 1024u)) && d_blk && blocks_batch(G);
-    // (1024: the previous generation of this path, kept for A/B: k_decode_long with a workgroup per 8192-word block)
+    const bool blocks_path = !gen && impl != 0 && !(G.dbg & (256u | 512u)) && d_blk && blocks_batch(G);
     const bool long_path = !blocks_path && !gen && impl != 0 && !(G.dbg & 256u) && G.uniform && long_waveform_batch(G.total_waves, G.u_wave_len);
     // a handful of chunks of long-enough waveforms: the parallel walk, then a plain decode launch
     const bool par_walk = d_pw && !tables_ready && !(G.dbg & 2048u) && G.uniform && G.n_chunks <= kPwMaxChunks &&
@@ -2663,31 +2529,13 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
             const uint32_t *fail = nullptr, *suspect = nullptr;
             hipError_t e = launch_decode_blocks(G, d_in, in_words, d_wave_off, d_wave_words, d_blk, d_status, d_out, &fail, &suspect, s);
             if (e != hipSuccess) return e;
-            k_decode_long<false><<<(unsigned)G.total_waves, kLongThreads, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_status, d_out,
-                                                                                 0u, nullptr, nullptr, nullptr, const_cast<uint32_t *>(fail), suspect);
+            k_decode_long<<<(unsigned)G.total_waves, kLongThreads, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_status, d_out, fail, suspect);
             mark(ev, 2, s);
             mark(ev, 3, s);
             return hipGetLastError();
         }
-        if (long_path) {
-            const uint32_t blocks_max = long_decode_blocks_max(G);
-            const uint64_t units = G.total_waves * blocks_max;
-            if (d_long && G.total_waves <= kLongMultiMaxWaves && !(G.dbg & 512u)) {
-                // scratch: uint64 state[units] | uint32 tail_end[units] | uint32 fail[total_waves] | uint32 ticket
-                uint64_t *state = d_long;
-                uint32_t *tail_end = reinterpret_cast<uint32_t *>(d_long + units);
-                uint32_t *fail = tail_end + units, *tick = fail + G.total_waves;
-                hipError_t e = hipMemsetAsync(d_long, 0, long_decode_scratch_bytes(G), s);
-                if (e != hipSuccess) return e;
-                k_long_tail<<<blocks_for(units, 64), 64, 0, s>>>(G, d_in, d_wave_off, d_wave_words, blocks_max, tail_end);
-                k_decode_long<true><<<(unsigned)units, kLongThreads, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_status, d_out,
-                                                                             blocks_max, tail_end, state, tick, fail);
-                k_decode_long<false><<<(unsigned)G.total_waves, kLongThreads, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_status, d_out,
-                                                                                     0u, nullptr, nullptr, nullptr, fail);
-            } else {
-                k_decode_long<false><<<(unsigned)G.total_waves, kLongThreads, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_status, d_out,
-                                                                                     0u, nullptr, nullptr, nullptr, nullptr);
-            }
+        if (long_path) {  // (flag 512, or a long-waveform batch the block decoder does not take: one workgroup per waveform)
+            k_decode_long<<<(unsigned)G.total_waves, kLongThreads, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_status, d_out, nullptr, nullptr);
             mark(ev, 2, s);
             mark(ev, 3, s);
             return hipGetLastError();

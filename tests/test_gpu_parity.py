@@ -425,7 +425,7 @@ def test_few_waveforms_take_the_block_decoder(ctx, O):
         ref_w, ref_off = O.encode_batch(x, N, opts)
         plan = ctx.plan_uniform(n_chunks, N, opts)
         enc = dr.EncodedBatch(dev(ctx, ref_w.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), ref_w.size)
-        for flags in (0, 256, 1024):
+        for flags in (0, 256, 512):
             ctx.set_option("debug_flags", flags)
             y = plan.decode(enc).cpu().numpy()
             assert np.array_equal(y, x), (n_chunks, W, L, k, kind, flags)
@@ -465,10 +465,10 @@ def test_few_long_waveforms_take_the_wave_per_waveform_decoder(ctx, O):
             ref_w, ref_off = O.encode_batch(x, n, opts)
             plan = ctx.plan_uniform(3, n, (opts[0], L))
             enc = dr.EncodedBatch(dev(ctx, ref_w.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), ref_w.size)
-            # 256: lane-per-waveform decoder / single-pass encoder; 512: one workgroup per waveform; 1024: the previous
-            # block decoder; 0: the defaults for such batches (a workgroup per block of the stream -- drx_blocks.hip --,
+            # 256: lane-per-waveform decoder / single-pass encoder; 512: one workgroup per waveform (the block decoder's
+            # fallback); 0: the defaults for such batches (a workgroup per block of the stream -- drx_blocks.hip --,
             # a wavefront per 8192-sample segment)
-            for flags in (256, 512, 1024, 0):
+            for flags in (256, 512, 0):
                 ctx.set_option("debug_flags", flags)
                 assert np.array_equal(plan.decode(enc).cpu().numpy(), x), (name, opts, flags)
                 w, off = plan.encode(dev(ctx, x)).to_numpy()

@@ -1,0 +1,9 @@
+#!/bin/bash
+# SQ counters of one workload with one library variant: tools/pmc_sq.sh variant workload tag
+R=${GRAFT_REPO_ROOT:-$PWD}; cd /tmp && export TMPDIR=/tmp; O=$R/gpurun_out/pmc_$3; rm -rf $O; mkdir -p $O; cd $R
+export DRX_LIB_PATH=$R/deltarice_amd/variants/lib_$1.so
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $O/a -o p --output-format csv -- python3 tools/workload.py $2 --steps 2 > $O/a.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_INSTS_VMEM_WR -d $O/b -o p --output-format csv -- python3 tools/workload.py $2 --steps 2 > $O/b.log 2>&1
+python3 profiles/pmc_summary.py $O/a/p_counter_collection.csv $O/b/p_counter_collection.csv > $O/summary.txt 2>&1
+grep -A18 "k_decode_blocks\|k_decode_lanes\|k_encode_fused" $O/summary.txt | head -60
+rm -rf $O/a $O/b

@@ -83,6 +83,7 @@ struct drx_plan {
     void *d_pw = nullptr;              // a handful of chunks: candidate lists of the parallel header walk
     void *d_blk = nullptr;             // few waveforms: unit table, look-back state and flags of the block-parallel decoder
     uint32_t *d_walk_lists = nullptr;  // ragged plans: chunk indices, short-waveform chunks first
+    uint2 *d_rag_order = nullptr;      // ragged plans: decode wavefronts, longest WaveformLength first
     uint32_t n_short = 0, n_long = 0;
     DevStatus *d_status = nullptr;
     DevStatus *h_status = nullptr;  // pinned
@@ -240,6 +241,7 @@ static void plan_free(drx_plan *p) {
     if (p->d_scan) (void)hipFree(p->d_scan);
     if (p->d_taps) (void)hipFree(p->d_taps);
     if (p->d_walk_lists) (void)hipFree(p->d_walk_lists);
+    if (p->d_rag_order) (void)hipFree(p->d_rag_order);
     if (p->d_seg_bits) (void)hipFree(p->d_seg_bits);
     if (p->d_seg_pos) (void)hipFree(p->d_seg_pos);
     if (p->d_seg_unit_base) (void)hipFree(p->d_seg_unit_base);
@@ -333,6 +335,21 @@ drx_status drx_plan_create(drx_ctx *ctx, uint64_t n_chunks, const uint32_t *chun
         p->G.n_short = p->n_short;
         p->G.n_long = p->n_long;
         p->G.max_groups = max_groups;
+        // decode order: wavefronts (groups of 64 waveforms of one chunk) by decreasing WaveformLength
+        {
+            std::vector<uint32_t> by_len(n_chunks);
+            for (uint64_t c = 0; c < n_chunks; ++c) by_len[c] = (uint32_t)c;
+            std::stable_sort(by_len.begin(), by_len.end(), [&](uint32_t a, uint32_t b) { return desc[a].wave_len > desc[b].wave_len; });
+            std::vector<uint2> order;
+            for (uint32_t c : by_len)
+                for (uint32_t j = 0; j < (desc[c].n_waves + 63u) / 64u; ++j) order.push_back(make_uint2(c, j));
+            if (order.size() <= 0x7fffffffull) {
+                if (e == hipSuccess) e = hipMalloc((void **)&p->d_rag_order, order.size() * sizeof(uint2));
+                if (e == hipSuccess) e = hipMemcpy(p->d_rag_order, order.data(), order.size() * sizeof(uint2), hipMemcpyHostToDevice);
+                p->G.rag_order = p->d_rag_order;
+                p->G.rag_groups = (uint32_t)order.size();
+            }
+        }
         // parallel header walks for small ragged batches: every long-waveform chunk within the chunk-wide walk's
         // capacity, every short-waveform chunk worth the two block passes (same limits as for uniform batches)
         {

@@ -63,10 +63,19 @@ __host__ __device__ __forceinline__ uint32_t min_payload_words(uint32_t len, uin
 
 // count-leading-zeros with the ISA's result for 0 (-1) instead of the source language's undefined behaviour: the
 // decoders meet an all-zero window only past the end of a corrupt stream, where any value will do, but it has to BE a value
+#ifndef DRX_FFBH_MODE
+#define DRX_FFBH_MODE 0
+#endif
 __device__ __forceinline__ uint32_t ffbh(uint32_t x) {
+#if DRX_FFBH_MODE == 0
     uint32_t r;
     asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(x));
     return r;
+#elif DRX_FFBH_MODE == 1
+    return (uint32_t)__builtin_clz(x | 1u);
+#else
+    return (uint32_t)__builtin_clz(x);  // (A/B only: undefined for 0 in the source language)
+#endif
 }
 
 struct WaveRef {

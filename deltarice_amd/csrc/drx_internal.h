@@ -57,6 +57,10 @@ struct Geom {
     // ragged batches small enough for the parallel header walks (drx_kernels.hip): set when the plan is made;
     // rag_bw_blocks_max = 4096-word blocks of the largest short-waveform chunk at 25 bits per sample
     uint32_t rag_par, rag_bw_blocks_max;
+    // ragged batches, lane-per-waveform decode outside the fused launch: {chunk, group of 64 waveforms} of every
+    // wavefront, longest WaveformLength first; rag_groups entries
+    const uint2 *rag_order;
+    uint32_t rag_groups;
 };
 
 struct DevStatus {

@@ -1967,6 +1967,21 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
             n = (uint32_t)(gr >> 32) & 0x7fffffffu;
             S = chunk_word_off[c] + (uint32_t)gr + 1u;
         }
+    } else if (!G.uniform && G.rag_order) {
+        // ragged batch: wavefronts in order of decreasing WaveformLength (longest processing time first).  A lane takes
+        // ~60 ns per sample whatever else runs, so a wavefront of 16 384-sample waveforms that starts last adds its
+        // whole 1 ms to the launch (config 5: 1.9 -> 1.2 ms)
+        const uint2 e = G.rag_order[blockIdx.x];  // {chunk, group of 64 waveforms inside it}
+        const ChunkDesc d = G.chunks[e.x];
+        const uint32_t idx = e.y * 64u + (uint32_t)lane;
+        active = idx < d.n_waves;
+        g = d.wave_base + idx;
+        if (active) {
+            len = (idx + 1 == d.n_waves) ? (d.n_samples - idx * d.wave_len) : d.wave_len;
+            ooff = d.sample_off + (uint64_t)idx * d.wave_len;
+            S = wave_off[g] + 1u;
+            n = wave_words[g];
+        }
     } else {
         g = (uint64_t)blockIdx.x * 64u + lane;
         active = g < G.total_waves;
@@ -2522,7 +2537,7 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                                                                              G.n_long, d_wave_off, d_wave_words, d_status);
         }
         mark(ev, 1, s);
-        const unsigned nb = blocks_for(G.total_waves, 64);
+        const unsigned nb_plain = blocks_for(G.total_waves, 64);
         if (blocks_path) {
             // a workgroup per block of every waveform (drx_blocks.hip); waveforms it flags are decoded again, one
             // workgroup each, by the kernel that also judges them
@@ -2542,8 +2557,9 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
         }
         if (impl == 5) impl = 1;  // (a batch that cannot take the in-launch walk)
         if (impl == 8) impl = 7;
+        const unsigned nb = (!G.uniform && G.rag_order) ? G.rag_groups : nb_plain;  // (groups per chunk round up)
         if (impl == 0)
-            k_decode_simple<<<nb, 64, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_status, d_out);
+            k_decode_simple<<<nb_plain, 64, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_status, d_out);
         else if (impl == 7 && gen)
             k_decode_lanes<64, 16, 64, 16, false, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out);
         else if (impl == 7)

@@ -74,7 +74,9 @@ drx_status drx_h5_read(drx_ctx *ctx, const char *file, const char *name, int16_t
     if (H5Pget_chunk(pl, 2, chunk) != 2 || chunk[1] != dims[1]) { rc = DRX_ERR_UNSUPPORTED; goto out; }
     {
         hid_t ty = H5Dget_type(d);
-        const int ok = H5Tget_class(ty) == H5T_INTEGER && H5Tget_size(ty) == 2;
+        /* 16-bit integers in the byte order the codec computes in; signed or unsigned alike (the reference reinterprets the
+         * bytes as int16 whatever the type, tests/test.py:72-83) */
+        const int ok = H5Tget_class(ty) == H5T_INTEGER && H5Tget_size(ty) == 2 && H5Tget_order(ty) == H5T_ORDER_LE;
         H5Tclose(ty);
         if (!ok) { rc = DRX_ERR_UNSUPPORTED; goto out; }
     }
@@ -103,7 +105,8 @@ drx_status drx_h5_read(drx_ctx *ctx, const char *file, const char *name, int16_t
     uint64_t words = 0;
     for (uint64_t c = 0; c < s.n_chunks; ++c) {
         hsize_t off[2] = {c * chunk[0], 0}, nb = 0;
-        if (H5Dget_chunk_storage_size(d, off, &nb) < 0 || nb == 0 || (nb & 3)) { rc = DRX_ERR_CORRUPT; goto out; }
+        if (H5Dget_chunk_storage_size(d, off, &nb) < 0 || (nb & 3)) { rc = DRX_ERR_CORRUPT; goto out; }
+        if (nb == 0) { rc = DRX_ERR_UNSUPPORTED; goto out; }  /* a chunk that was never written (fill value): not a stored stream */
         h_off[c] = words;
         words += nb / 4;
     }
@@ -163,7 +166,14 @@ out:
 drx_status drx_h5_write(drx_ctx *ctx, const char *file, const char *name, const int16_t *d_in,
                         uint64_t rows, uint64_t cols, uint64_t chunk_rows, unsigned rice_m,
                         unsigned wave_len, drx_h5_stats *st) {
+    return drx_h5_write_filtered(ctx, file, name, d_in, rows, cols, chunk_rows, rice_m, wave_len, 0, NULL, st);
+}
+
+drx_status drx_h5_write_filtered(drx_ctx *ctx, const char *file, const char *name, const int16_t *d_in,
+                                 uint64_t rows, uint64_t cols, uint64_t chunk_rows, unsigned rice_m,
+                                 unsigned wave_len, unsigned n_taps, const int32_t *taps, drx_h5_stats *st) {
     if (!ctx || !file || !name || !d_in || !rows || !cols || !chunk_rows || chunk_rows > rows) return DRX_ERR_ARG;  /* HDF5: chunk <= dataset */
+    if (n_taps > DRX_MAX_TAPS || (n_taps && !taps)) return DRX_ERR_ARG;
     drx_h5_stats s;
     memset(&s, 0, sizeof s);
     unsigned k;
@@ -185,6 +195,7 @@ drx_status drx_h5_write(drx_ctx *ctx, const char *file, const char *name, const 
     if (hipMalloc((void **)&d_off, (s.n_chunks + 3) * 8) != hipSuccess) { rc = DRX_ERR_NOMEM; goto out; }
     if (n_full) {
         if ((rc = drx_plan_create_uniform(ctx, n_full, chunk_samples, wave_len, k, &plan)) != DRX_OK) goto out;
+        if (n_taps && (rc = drx_plan_set_filter(plan, n_taps, taps)) != DRX_OK) goto out;
         cap = drx_plan_max_encoded_words(plan);
         if (hipMalloc(&d_words, cap * 4) != hipSuccess) { rc = DRX_ERR_NOMEM; goto out; }
         if ((rc = drx_encode(plan, d_in, (uint32_t *)d_words, cap, d_off)) != DRX_OK) goto out;
@@ -192,6 +203,7 @@ drx_status drx_h5_write(drx_ctx *ctx, const char *file, const char *name, const 
     }
     if (edge_rows) {
         if ((rc = drx_plan_create_uniform(ctx, 1, chunk_samples, wave_len, k, &plan_edge)) != DRX_OK) goto out;
+        if (n_taps && (rc = drx_plan_set_filter(plan_edge, n_taps, taps)) != DRX_OK) goto out;
         cap_e = drx_plan_max_encoded_words(plan_edge);
         if (hipMalloc(&d_edge, (size_t)chunk_samples * 2) != hipSuccess || hipMalloc(&d_words_e, cap_e * 4) != hipSuccess) { rc = DRX_ERR_NOMEM; goto out; }
         if (hipMemsetAsync(d_edge, 0, (size_t)chunk_samples * 2, stream) != hipSuccess ||
@@ -222,8 +234,9 @@ drx_status drx_h5_write(drx_ctx *ctx, const char *file, const char *name, const 
     hsize_t dims[2] = {rows, cols}, chunk[2] = {chunk_rows, cols};
     sp = H5Screate_simple(2, dims, NULL);
     pl = H5Pcreate(H5P_DATASET_CREATE);
-    const unsigned cd[2] = {rice_m, wave_len ? wave_len : 0xffffffffu};
-    if (H5Pset_chunk(pl, 2, chunk) < 0 || H5Pset_filter(pl, FILTER_ID, H5Z_FLAG_MANDATORY, 2, cd) < 0) goto out;
+    unsigned cd[3 + DRX_MAX_TAPS] = {rice_m, wave_len ? wave_len : 0xffffffffu, n_taps};  /* src/deltaRice.c:248-291 */
+    for (unsigned j = 0; j < n_taps; ++j) cd[3 + j] = (unsigned)taps[j];
+    if (H5Pset_chunk(pl, 2, chunk) < 0 || H5Pset_filter(pl, FILTER_ID, H5Z_FLAG_MANDATORY, n_taps ? 3 + n_taps : 2, cd) < 0) goto out;
     if ((d = H5Dcreate2(f, name, H5T_NATIVE_SHORT, sp, H5P_DEFAULT, pl, H5P_DEFAULT)) < 0) goto out;
     for (uint64_t c = 0; c < s.n_chunks; ++c) {
         hsize_t off[2] = {c * chunk_rows, 0};

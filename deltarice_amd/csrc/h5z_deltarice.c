@@ -70,7 +70,7 @@ int init_filter(const char *libname) {
     void *h = dlopen(libname, RTLD_LAZY | RTLD_LOCAL);
     if (!h) return -1;
     h5zregister_fn f = (h5zregister_fn)dlsym(h, "H5Zregister");
-    if (!f) return -1;
+    if (!f) { dlclose(h); return -1; }  /* not a library that carries HDF5: try the next one (src/h5.pyx:43-51) */
     g_h5zregister = f;
     return 0;
 }

@@ -38,6 +38,9 @@ def _load():
         L.drx_h5_write.restype = C.c_int
         L.drx_h5_write.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                    C.c_uint64, C.c_uint, C.c_uint, C.POINTER(Stats)]
+        L.drx_h5_write_filtered.restype = C.c_int
+        L.drx_h5_write_filtered.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                            C.c_uint64, C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_int32), C.POINTER(Stats)]
         _io = L
     return _io
 
@@ -53,12 +56,15 @@ def read(ctx: Context, path: str, name: str, out: torch.Tensor) -> dict:
 
 
 def write(ctx: Context, path: str, name: str, x: torch.Tensor, rows: int, cols: int, chunk_rows: int,
-          rice_m: int = 8, wave_len: int | None = None) -> dict:
-    """VRAM -> file.  x: contiguous int16 tensor [rows*cols] on ctx.device."""
+          rice_m: int = 8, wave_len: int | None = None, taps=None) -> dict:
+    """VRAM -> file.  x: contiguous int16 tensor [rows*cols] on ctx.device.  taps: a general prediction filter
+    (compression_opts[3:], src/deltaRice.c:277-289 of the reference); None: the delta filter."""
     st = Stats()
     ctx.stream.wait_stream(torch.cuda.current_stream(ctx.device))
-    rc = _load().drx_h5_write(ctx._h, os.fsencode(path), name.encode(), x.data_ptr(), rows, cols, chunk_rows,
-                              rice_m, cols if wave_len is None else wave_len, C.byref(st))
+    taps = [int(t) for t in (taps or ())]
+    tarr = (C.c_int32 * max(len(taps), 1))(*taps)
+    rc = _load().drx_h5_write_filtered(ctx._h, os.fsencode(path), name.encode(), x.data_ptr(), rows, cols, chunk_rows,
+                                       rice_m, cols if wave_len is None else wave_len, len(taps), tarr, C.byref(st))
     if rc != _lib.DRX_OK:
         raise _lib.DeltaRiceError(rc, f"drx_h5_write({path!r}, {name!r})")
     return st.as_dict()

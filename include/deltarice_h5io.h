@@ -9,8 +9,9 @@
  * 1.10.3, no filter pipeline involved), one PCIe copy, and ONE drx_decode / drx_encode over the
  * whole batch.  Files are bit-compatible both ways with the filter path and with the reference.
  *
- * Datasets: 2-D, 16-bit integers, chunked as (chunk_rows x all columns), rows divisible by
- * chunk_rows, filter 32025 with cd_values = (RiceParameter, WaveformLength) (the delta filter).
+ * Datasets: 2-D, 16-bit little-endian integers (signed or unsigned: the bytes are what is coded), chunked as
+ * (chunk_rows x all columns), filter 32025 alone in the pipeline with any cd_values the filter accepts.  A chunk
+ * that was never written (fill value only) is DRX_ERR_UNSUPPORTED, another element type or byte order likewise.
  * This library links libhdf5 (the application's); the codec itself stays in libdeltarice_hip.so.
  */
 #ifndef DELTARICE_H5IO_H
@@ -39,6 +40,12 @@ drx_status drx_h5_read(drx_ctx *ctx, const char *file, const char *name, int16_t
 drx_status drx_h5_write(drx_ctx *ctx, const char *file, const char *name, const int16_t *d_in,
                         uint64_t rows, uint64_t cols, uint64_t chunk_rows, unsigned rice_m,
                         unsigned wave_len, drx_h5_stats *stats);
+
+/* The same with a general prediction filter (cd_values[2..] = n_taps, taps..., src/deltaRice.c:277-289); n_taps = 0:
+ * the delta filter, cd_values = (RiceParameter, WaveformLength) as drx_h5_write stores them. */
+drx_status drx_h5_write_filtered(drx_ctx *ctx, const char *file, const char *name, const int16_t *d_in,
+                                 uint64_t rows, uint64_t cols, uint64_t chunk_rows, unsigned rice_m,
+                                 unsigned wave_len, unsigned n_taps, const int32_t *taps, drx_h5_stats *stats);
 
 #ifdef __cplusplus
 }

@@ -89,6 +89,15 @@ def test_direct_read_rejects_what_it_does_not_handle(env, h5tool, tmp_path):
     y = torch.empty(8 * 1024, dtype=torch.int16, device=ctx.device)
     h5io.read(ctx, str(f), "test", y)  # files written with a general filter are read too
     assert np.array_equal(y.cpu().numpy(), x.reshape(-1))
+    # ... and can be written directly: same stored bytes as through the filter callback
+    f2 = tmp_path / "fir_direct.h5"
+    h5io.write(ctx, str(f2), "test", torch.from_numpy(x.reshape(-1)).to(ctx.device), 8, 1024, 2, 8, 1024, taps=(1, -1, 1, -1))
+    n = int(h5tool("chunks", f, tmp_path / "a").stdout)
+    assert n == int(h5tool("chunks", f2, tmp_path / "b").stdout) == 4
+    for c in range(n):
+        assert open(f"{tmp_path}/a.{c}", "rb").read() == open(f"{tmp_path}/b.{c}", "rb").read()
+    h5tool("read", f2, tmp_path / "back.bin")  # and the filter callback reads the directly written file
+    assert np.array_equal(np.fromfile(tmp_path / "back.bin", np.int16), x.reshape(-1))
     with pytest.raises(dr.DeltaRiceError):
         h5io.read(ctx, str(tmp_path / "missing.h5"), "test", y)
     with pytest.raises(dr.DeltaRiceError) as e:

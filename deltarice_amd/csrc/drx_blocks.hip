@@ -25,24 +25,31 @@
 //             blocks of the waveform ({status | count | sum} entries, tickets as in the encoder).  A block that has to
 //             correct its start after it published its end flags the waveform; flagged waveforms are decoded again
 //             by the one-workgroup-per-waveform kernel (drx_kernels.hip), which is also the one that judges them.
-//   phase 2   every lane decodes its cnt_j codes again from f_j, now with the running sum, into an LDS staging
-//             buffer in OUTPUT order (its first sample index is the prefix sum of the counts); the block then
-//             copies whole aligned 128-byte lines to HBM.  (Scattered 2- and 8-byte stores of the previous
-//             long-waveform kernel cost 2.5-5.4 x the output size in HBM writes: profiles/r02_*_pmc_traffic.json.)
-// Two parses of every bit (1.4 + 1), no iteration in the common case, no sample ever stored twice.
+//   phase 2   phase 1 has left every lane's running sums (relative to its first code) in LDS, lane-major; once the
+//             prefix sums over counts and sums are known each lane reads its own into registers, adds its base and
+//             writes them to the same buffer in OUTPUT order; the block then copies whole aligned 128-byte lines to
+//             HBM.  (Scattered 2- and 8-byte stores of the previous long-waveform kernel cost 2.5-5.4 x the output
+//             size in HBM writes: profiles/r02_*_pmc_traffic.json.)  A block in which some lane holds more codes than
+//             its share of the buffer (kBlkLaneCap; long runs of tiny residuals) decodes a second time instead, in
+//             as many staging passes as it needs.
+// 1.4 parses of every bit in the common case, no iteration, no sample ever stored twice.
 // Delta filter only: the prefix sum over residual sums is what makes blocks independent.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "drx_device.h"
 #include "drx_internal.h"
 
 namespace drx {
 
-constexpr int kBlkSegW = 13;             // words per lane (odd)
+constexpr int kBlkSegW = 11;             // words per lane (odd): 54 samples at 6.5 bits per sample
+constexpr uint32_t kBlkLaneCap = 76;     // samples a lane can leave in its share of the staging buffer (+ 4.8 sigma)
+constexpr uint32_t kBlkLaneStride = kBlkLaneCap / 2u + 1u;  // dwords per lane: 38 of samples + a dump slot (odd: no bank conflicts)
 constexpr uint32_t kBlkPre = 8;          // words kept in front of a block: lane 0's run-up
-constexpr uint32_t kBlkGuessBits = 160;  // run-up in front of a segment (a parse is in step after a few codes; 96, 128
-                                         // and 224 bits measured: within 4 % of one another, profiles/r02_notes.md)
+constexpr uint32_t kBlkGuessBits = 128;  // run-up in front of a segment (a parse is in step after a few codes; 96, 128,
+                                         // 160 and 224 bits measured: within 4 % of one another, profiles/r02_notes.md)
+constexpr uint32_t kBlkRun = 4;          // consecutive blocks of a waveform per ticket, when waveforms outnumber workgroups
 constexpr uint32_t kBlkTail = 4;         // words behind a block: a code that starts inside may end 24 bits behind it,
                                          // and a window reads three words
 
@@ -50,36 +57,59 @@ template <int NT>
 struct BlkGeom {
     static constexpr uint32_t kWords = NT * kBlkSegW;                       // payload words per block
     static constexpr uint32_t kLdsWords = kBlkPre + kWords + kBlkTail + 4;  // + up to 3 words of 16-byte alignment
-    static constexpr uint32_t kOutCap = NT * 72;                            // samples staged per copy-out (a segment holds
-                                                                            // 64 at 6.5 bits per sample; more: further passes)
+    static constexpr uint32_t kOutCap = NT * kBlkLaneCap;                   // samples staged per copy-out
+    static constexpr uint32_t kStageWords = NT * kBlkLaneStride;            // the staging buffer, lane-major or output order
     static_assert(kLdsWords % 4 == 0, "the image is filled by 16-byte pieces");
 };
 
 __host__ __device__ inline uint32_t blk_words(uint32_t nt) { return nt * kBlkSegW; }
 
-// unit = (waveform, block); unit_first[g] = first unit of waveform g, unit_first[W] = their number.  One workgroup.
-__global__ __launch_bounds__(1024) void k_blk_units(uint64_t total_waves, const uint32_t *__restrict__ wave_words,
-                                                    uint32_t words_per_block, uint32_t *__restrict__ unit_first) {
-    __shared__ uint32_t wsum[16];
+// Most blocks any waveform of the batch has: info[0]; tickets of the decode launch: info[1] = info[0] x waveforms.
+// One workgroup.
+__global__ __launch_bounds__(1024) void k_blk_max(uint64_t total_waves, const uint32_t *__restrict__ wave_words,
+                                                  uint32_t words_per_block, uint32_t *__restrict__ info) {
+    __shared__ uint32_t wmax[16];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
-    uint32_t run = 0;
-    for (uint64_t i0 = 0; i0 < total_waves; i0 += 1024) {
-        const uint64_t i = i0 + threadIdx.x;
-        const uint32_t v = (i < total_waves) ? (wave_words[i] + words_per_block - 1u) / words_per_block : 0u;
-        const uint32_t inc = wave_incl_scan_dpp(v);
-        if (lane == 63) wsum[wv] = inc;
-        __syncthreads();
-        uint32_t before = 0, all = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) { before += (w < wv) ? wsum[w] : 0u; all += wsum[w]; }
-        if (i < total_waves) unit_first[i] = run + before + inc - v;
-        run += all;
-        __syncthreads();
+    uint32_t m = 0;
+    for (uint64_t i = threadIdx.x; i < total_waves; i += 1024) {
+        const uint32_t v = (wave_words[i] + words_per_block - 1u) / words_per_block;
+        m = v > m ? v : m;
     }
-    if (threadIdx.x == 0) unit_first[total_waves] = run;
+    m = wave_max_u32(m);
+    if (lane == 0) wmax[wv] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) m = wmax[w] > m ? wmax[w] : m;
+        info[0] = m;
+        const uint64_t t = (uint64_t)m * total_waves;
+        info[1] = t > 0xffffffffull ? 0xffffffffu : (uint32_t)t;
+    }
+}
+
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() also fences global memory, i.e. waits for
+// every global load and store the wave has in flight (s_waitcnt vmcnt(0)): the image and the ticket fetched ahead and
+// the output lines being written would all be waited for at the next barrier, which is exactly what fetching ahead is
+// meant to avoid.  Nothing this kernel exchanges between the waves of a workgroup goes through global memory.
+__device__ __forceinline__ void blk_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 enum { kBlkSkip = 0, kBlkCount = 1, kBlkValue = 2 };
+
+// Diagnostic build (-DDRX_BLK_STAMPS, never shipped): thread 0 of every workgroup adds the cycles between phase
+// boundaries into prof[]; launch_decode_blocks prints the shares.
+#ifdef DRX_BLK_STAMPS
+#define BLK_STAMP(i)                                                                                         \
+    do {                                                                                                     \
+        if (tid == 0) {                                                                                      \
+            const unsigned long long t_now = __builtin_amdgcn_s_memtime();                                   \
+            atomicAdd(prof + (i), t_now - t_prev);                                                           \
+            t_prev = t_now;                                                                                  \
+        }                                                                                                    \
+    } while (0)
+#else
+#define BLK_STAMP(i) do { } while (0)
+#endif
 
 // count-leading-zeros that is defined for 0 (any value will do there: an all-zero window exists only in a corrupt stream)
 __device__ __forceinline__ uint32_t clz_nz(uint32_t x) { return (uint32_t)__builtin_clz(x | 1u); }
@@ -89,7 +119,7 @@ __device__ __forceinline__ uint32_t clz_nz(uint32_t x) { return (uint32_t)__buil
 // W[Qp >> 5 .. + 2] are the window's words, last one first, and v_alignbit(hi, lo, Qp) is its first half -- also on a
 // word boundary (as in k_decode_lanes).  nu = minus the code length; v_bfe_u32 / v_alignbit_b32 read 5 bits of their
 // offset / shift, ~t == 31 - t (mod 32) serves both.
-struct BlkPair { uint32_t nu1, nu2, z1, z2; };
+struct BlkPair { uint32_t nu1, nu2, z1, z2; bool pad1, pad2; };
 template <bool VALUES>
 __device__ __forceinline__ BlkPair blk_pair(const uint32_t *W, uint32_t k, uint32_t Qp) {
     const uint32_t idx = Qp >> 5;
@@ -104,6 +134,8 @@ __device__ __forceinline__ BlkPair blk_pair(const uint32_t *W, uint32_t k, uint3
     const uint32_t q2 = clz_nz(win2);
     const uint32_t kk2 = (win2 < (1u << 24)) ? 16u : k;
     r.nu2 = ~(q2 + kk2);
+    r.pad1 = winA < (1u << 23);  // nine zero bits: not a code
+    r.pad2 = win2 < (1u << 23);
     r.z1 = r.z2 = 0;
     if (VALUES) {
         r.z1 = (q1 << kk1) + __builtin_amdgcn_ubfe(winA, r.nu1, kk1);
@@ -115,13 +147,17 @@ __device__ __forceinline__ uint32_t unzigzag(uint32_t z) { return (z >> 1) ^ (0u
 
 // The parse.
 //   kBlkSkip / kBlkCount: codes are taken while they START before the limit (Qp > qlim);
-//   kBlkValue: exactly `cmax` codes (c counts them), each running sum (:80-89) stored as int16 at outp[c].
+//     kBlkCount also leaves the running sums (:80-89, from 0 at the lane's first code) in `stage`, two per dword,
+//     pair c / 2 at stage[min(c / 2, kBlkLaneCap / 2)] (the last dword is a dump slot), and stops at a window that
+//     opens with nine zero bits: no code does (q < 8: '1' within nine bits, escape: eight zeros then '1',
+//     :215-228), so that is the zero padding behind the waveform's last code, not a sample;
+//   kBlkValue: exactly `cmax` codes (c counts them), each running sum stored as int16 at outp[c].
 // A lane that is not enabled keeps its state.  (A variant that ran a wave without per-code masks while every lane had
 // room for two more codes, and only the last few codes masked, was measured 4-8 % SLOWER: the vote per pair and the
 // second loop cost what the masks had: profiles/r02_notes.md.)
 template <int MODE>
 __device__ __forceinline__ void blk_parse(const uint32_t *W, uint32_t k, bool enable, uint32_t &Qp, uint32_t qlim,
-                                          uint32_t &c, uint32_t &sum, uint32_t cmax, uint16_t *outp) {
+                                          uint32_t &c, uint32_t &sum, uint32_t cmax, uint16_t *outp, uint32_t *stage = nullptr) {
     auto more = [&](uint32_t q, uint32_t cc) __attribute__((always_inline)) {
         return enable && (MODE == kBlkValue ? cc < cmax : (int32_t)(q - qlim) > 0);
     };
@@ -129,15 +165,23 @@ __device__ __forceinline__ void blk_parse(const uint32_t *W, uint32_t k, bool en
 #pragma unroll
         for (int u = 0; u < 2; ++u) {  // one vote per four codes
             const BlkPair p = blk_pair<MODE != kBlkSkip>(W, k, Qp);
-            const bool act1 = more(Qp, c);
+            bool act1 = more(Qp, c);
             const uint32_t Qa = Qp + p.nu1;
-            const bool act2 = act1 && more(Qa, c + 1u);
+            bool act2 = act1 && more(Qa, c + 1u);
+            if (MODE == kBlkCount) {
+                if (act1 && p.pad1) { act1 = act2 = false; qlim = Qp; }  // (Qp stays: where the padding starts)
+                if (act2 && p.pad2) { act2 = false; qlim = Qa; }
+            }
             if (MODE != kBlkSkip) {
                 const uint32_t s1 = sum + unzigzag(p.z1);
                 const uint32_t s2 = s1 + unzigzag(p.z2);
                 if (MODE == kBlkValue) {
                     if (act1) outp[c] = (uint16_t)s1;
                     if (act2) outp[c + 1u] = (uint16_t)s2;
+                }
+                if (MODE == kBlkCount) {  // c is even here: only a lane's last pair can end after its first code
+                    const uint32_t slot = (c >> 1) < kBlkLaneCap / 2u ? (c >> 1) : kBlkLaneCap / 2u;
+                    if (act1) stage[slot] = __builtin_amdgcn_perm(s2, s1, 0x05040100u);
                 }
                 sum = act2 ? s2 : (act1 ? s1 : sum);
             }
@@ -151,20 +195,22 @@ template <int NT>
 __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
                                                       const uint64_t *__restrict__ wave_off,
                                                       const uint32_t *__restrict__ wave_words,
-                                                      const uint32_t *__restrict__ unit_first, uint64_t *__restrict__ state,
+                                                      const uint32_t *__restrict__ info, uint32_t slots_per_wave,
+                                                      uint32_t run_len, uint64_t *__restrict__ state,
                                                       uint32_t *__restrict__ ends, uint32_t *__restrict__ ticket,
                                                       uint32_t *__restrict__ fail, uint32_t *__restrict__ suspect,
-                                                      DevStatus *st, int16_t *__restrict__ out) {
+                                                      DevStatus *st, int16_t *__restrict__ out, unsigned long long *prof) {
     using BG = BlkGeom<NT>;
     constexpr uint32_t K = BG::kLdsWords + 2u;  // word w of the image sits at W[K + 1 - w]; K = 2 (mod 4): 16-byte quads
     constexpr uint32_t C = 32u * K;
     constexpr int NW = NT / 64;
     constexpr uint32_t kSegBits = 32u * kBlkSegW;
     // one LDS object, the image first: its three-word windows are read with immediate offsets from address 0
-    constexpr uint32_t kWSize = BG::kLdsWords + 4u, kObufWords = (BG::kOutCap + 16u) / 2u;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[kWSize + kObufWords + NT + 2 * NW + 4 + 2];
+    constexpr uint32_t kWSize = BG::kLdsWords + 4u, kObufWords = BG::kStageWords;  // (kOutCap + 8 samples fit: NT >= 8)
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kWSize + kObufWords + NT + 2 * NW + 4 + 8];  // (+ s_unit, s_pred, s_next, s_vote[3])
     uint32_t *const W = lds;
-    uint16_t *const obuf = reinterpret_cast<uint16_t *>(lds + kWSize);
+    uint32_t *const stage = lds + kWSize;                        // phase 1: lane-major, kBlkLaneStride dwords per lane
+    uint16_t *const obuf = reinterpret_cast<uint16_t *>(stage);  // phase 2: the block's samples in output order
     uint32_t *const s_e = lds + kWSize + kObufWords;
     uint32_t(*const s_tot)[NW] = reinterpret_cast<uint32_t(*)[NW]>(s_e + NT);
     uint64_t *const s_b = reinterpret_cast<uint64_t *>(s_e + NT + 2 * NW);  // (kWSize, kObufWords, NT, 2 NW: all even)
@@ -172,203 +218,356 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
     const uint32_t tid = threadIdx.x;
     const int lane = lane_id(), wv = (int)(tid >> 6);
     const uint32_t k = G.k;
-    const uint32_t total_units = unit_first[G.total_waves];
-    const bool vec_ok = ((uintptr_t)in & 15u) == 0;
+    // A ticket is a RUN of run_len consecutive blocks of one waveform, dealt run-major: run 0 of every waveform, then run 1
+    // of every waveform, ...  Inside a run only its first block talks to other workgroups (where the predecessor's
+    // stream ended, the look-back for samples and sum in front of it); the others start exactly where the block before
+    // them ended, with counts carried in registers.  The host makes runs longer than one block only when there are more
+    // waveforms than workgroups: two runs of ONE waveform in flight together serialise (the later one's look-back waits
+    // for the earlier one's last block).  The image of the next block -- of this run or of the next ticket's -- travels
+    // while the current block's samples are put in order and written out, and the next ticket is drawn a run ahead.
+    // In-kernel stamps of the first version (a ticket per block, waveform-major: 768 blocks of ONE 14 M-sample waveform
+    // in flight, every one polling twelve windows of aggregates) had 11 % of a workgroup's time in the parse and 77 % in
+    // four waits: ticket, image, predecessor's end, look-back (profiles/r02_notes.md).
+    const uint32_t n_waves32 = (uint32_t)G.total_waves;
+    const uint32_t max_runs = (info[0] + run_len - 1u) / run_len;
+    const uint64_t total_units64 = (uint64_t)max_runs * n_waves32;
+    const uint32_t total_units = total_units64 > 0xffffffffull ? 0xffffffffu : (uint32_t)total_units64;
     typedef uint16_t __attribute__((address_space(1))) g_u16;
     typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
     typedef u32x4v __attribute__((address_space(1))) g_uint4;
+    constexpr int NQ = (int)((BG::kLdsWords / 4u + NT - 1u) / NT);  // 16-byte pieces of an image per thread
 
-    for (;;) {
-        // units by ticket: every lower unit is held by a running (or finished) workgroup, so waiting for a
-        // predecessor cannot deadlock whatever the dispatch order; the grid is sized to be resident
-        if (tid == 0) s_unit = atomicAdd(ticket, 1u);
-        __syncthreads();
-        const uint32_t unit = s_unit;
-        __syncthreads();
-        if (unit >= total_units) return;
-        uint32_t glo = 0, ghi = (uint32_t)G.total_waves;  // last g with unit_first[g] <= unit
-        while (ghi - glo > 1u) {
-            const uint32_t mid = (glo + ghi) >> 1;
-            if (unit_first[mid] <= unit) glo = mid; else ghi = mid;
+#ifdef DRX_BLK_STAMPS
+    unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#endif
+    // tickets: every lower ticket is held by a running (or finished) workgroup, so waiting for a predecessor cannot
+    // deadlock whatever the dispatch order; the grid is sized to be resident
+    uint32_t &s_next = s_e[NT + 2 * NW + 6];
+    uint32_t *const s_vote = s_e + NT + 2 * NW + 8;  // [3], in rotation, so that a vote needs one barrier
+    uint32_t vote_no = 0;
+    // true in every thread if `v` holds in any thread of the workgroup.  Vote i uses word i mod 3; thread 0 clears the word
+    // of vote i + 1 on its way into vote i: every thread has passed the barrier of vote i - 1 by then, so none still
+    // reads the word of vote i - 2 (the same word), and the word of vote i - 1, which slow threads may still read, is another.
+    auto wg_any = [&](bool v) __attribute__((always_inline)) {
+        uint32_t *w = s_vote + vote_no % 3u;
+        if (__any(v) && lane == 0) __hip_atomic_fetch_or(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (tid == 0) s_vote[(vote_no + 1u) % 3u] = 0u;
+        blk_barrier();
+        ++vote_no;
+        return *w != 0u;
+    };
+    if (tid == 0) { s_unit = atomicAdd(ticket, 1u); s_vote[0] = 0u; s_vote[1] = 0u; s_vote[2] = 0u; }
+    __syncthreads();
+    uint32_t unit = s_unit;
+    __syncthreads();
+    // where a ticket's run lies: waveform, first block, payload
+    struct RunRef { uint64_t g, pay_lo; uint32_t n, blk_lo, blk_hi; };
+    auto run_of = [&](uint32_t u) __attribute__((always_inline)) {
+        RunRef q;
+        const uint32_t run = u / n_waves32;
+        q.g = u - run * n_waves32;
+        q.pay_lo = wave_off[q.g] + 1u;
+        q.n = wave_words[q.g];
+        const uint32_t n_blocks = (q.n + BG::kWords - 1u) / BG::kWords;
+        q.blk_lo = run * run_len;
+        q.blk_hi = (q.blk_lo + run_len < n_blocks) ? q.blk_lo + run_len : n_blocks;  // (blk_lo >= n_blocks: an empty run)
+        return q;
+    };
+    // image of block b: words [b kWords - kBlkPre, (b + 1) kWords + kBlkTail) of the payload, from a 16-byte boundary
+    auto image_base = [&](uint64_t pay_lo, uint32_t b) { return ((int64_t)(pay_lo + (uint64_t)b * BG::kWords) - (int64_t)kBlkPre) & ~(int64_t)3; };
+    // The fetch is unconditional 16-byte loads from a clamped address and nothing else: a load inside a branch is waited
+    // for at the end of that branch, which would put the whole round trip back in front of the parse.  What the clamp
+    // and the payload's end invalidate is sorted out when the registers are written to LDS.  (in_words >= 64 here: the
+    // host gives this decoder waveforms of 2048 samples and more.)
+    const int64_t a_max = (int64_t)in_words - 4;
+    auto fetch_image = [&](const RunRef &q, uint32_t b, uint4 (&v)[NQ]) __attribute__((always_inline)) {
+        const int64_t al = image_base(q.pay_lo, b);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int64_t a = al + 4 * (int64_t)(tid + (uint32_t)i * NT);
+            const int64_t ac = a < 0 ? 0 : (a > a_max ? a_max : a);
+            v[i] = *reinterpret_cast<const uint4 *>(in + ac);
         }
-        const uint64_t g = glo;
-        const uint32_t blk = unit - unit_first[g];
+    };
+    auto store_image = [&](const RunRef &q, uint32_t b, const uint4 (&v)[NQ]) __attribute__((always_inline)) {
+        const int64_t al = image_base(q.pay_lo, b);
+        const int64_t pay_hi = (int64_t)(q.pay_lo + q.n);  // nothing behind the payload is read as stream
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const uint32_t qd = tid + (uint32_t)i * NT;
+            const int64_t a = al + 4 * (int64_t)qd;
+            if (qd >= BG::kLdsWords / 4u) continue;
+            uint4 w = v[i];
+            if (a < 0 || a > a_max) {  // the clamp moved this piece: word by word (the first and the last piece of a batch)
+                auto ld = [&](int64_t j) { return (j >= 0 && j < (int64_t)in_words) ? in[j] : 0u; };
+                w = make_uint4(ld(a), ld(a + 1), ld(a + 2), ld(a + 3));
+            }
+            w.x = (a + 0 < pay_hi) ? w.x : 0u;
+            w.y = (a + 1 < pay_hi) ? w.y : 0u;
+            w.z = (a + 2 < pay_hi) ? w.z : 0u;
+            w.w = (a + 3 < pay_hi) ? w.w : 0u;
+            // words 4q .. 4q+3 at W[K - 4q - 2 .. K - 4q + 1]: one 16-byte store (K - 4q - 2 = kLdsWords - 4q)
+            *reinterpret_cast<uint4 *>(W + (BG::kLdsWords - 4u * qd)) = make_uint4(w.w, w.z, w.y, w.x);
+        }
+    };
+    if (unit >= total_units) return;
+    RunRef cur = run_of(unit);
+    uint4 img[NQ];
+    if (cur.blk_lo < cur.blk_hi) fetch_image(cur, cur.blk_lo, img);
+    for (;;) {
+        // the next ticket, drawn a run ahead.  Inline asm: a returning atomic the compiler sees inside `if (tid == 0)` is
+        // waited for at the end of that branch; this one is waited for where its value is used
+        uint32_t next_ticket = 0;
+        if (tid == 0) asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(next_ticket) : "v"(0u), "v"(1u), "s"(ticket) : "memory");
+        BLK_STAMP(0);  // ticket
+        const uint64_t g = cur.g, pay_lo = cur.pay_lo;
+        const uint32_t n = cur.n, blk_lo = cur.blk_lo, blk_hi = cur.blk_hi;
         const WaveRef r = locate(G, g);
-        const uint64_t pay_lo = wave_off[g] + 1u;
-        const uint32_t n = wave_words[g], len = r.len;
+        const uint32_t len = r.len;
         int16_t *y = out + r.sample_off;
         const uint32_t n_blocks = (n + BG::kWords - 1u) / BG::kWords;
-        const uint32_t w0 = blk * BG::kWords;
-        const uint32_t avail = (n - w0 < BG::kWords) ? n - w0 : BG::kWords;
-
-        // ---- the block's image in LDS: words [w0 - kBlkPre, w0 + kWords + kBlkTail), from a 16-byte boundary ----
-        const int64_t a_first = (int64_t)(pay_lo + w0) - (int64_t)kBlkPre;
-        const int64_t al = a_first & ~(int64_t)3;
-        const uint32_t s_i0 = (uint32_t)((int64_t)(pay_lo + w0) - al);  // image index of the block's first word
-        const int64_t pay_hi = (int64_t)(pay_lo + n);                    // nothing behind the payload is read as stream
-        for (uint32_t q = tid; q < BG::kLdsWords / 4u; q += NT) {
-            const int64_t a = al + 4 * (int64_t)q;
-            uint4 v;
-            if (vec_ok && a >= 0 && a + 4 <= (int64_t)in_words && a + 4 <= pay_hi) {
-                v = *reinterpret_cast<const uint4 *>(in + a);
-            } else {
-                auto ld = [&](int64_t i) { return (i >= 0 && i < (int64_t)in_words && i < pay_hi) ? in[i] : 0u; };
-                v = make_uint4(ld(a), ld(a + 1), ld(a + 2), ld(a + 3));
-            }
-            // words 4q .. 4q+3 at W[K - 4q - 2 .. K - 4q + 1]: one 16-byte store (K - 4q - 2 = kLdsWords - 4q)
-            *reinterpret_cast<uint4 *>(W + (BG::kLdsWords - 4u * q)) = make_uint4(v.w, v.z, v.y, v.x);
-        }
-        __syncthreads();
-
-        // ---- phase 1: where the codes of my segment start, how many there are, what they sum to ----
-        const uint32_t B0 = 32u * s_i0, bend = B0 + 32u * avail;
-        const uint32_t bj = B0 + kSegBits * tid;
-        const bool active = bj < bend;
-        const uint32_t lim = (bj + kSegBits < bend) ? bj + kSegBits : bend;
-        const bool exact0 = tid == 0 && blk == 0;  // the waveform's first code starts at bit 0
-        uint32_t Qp = C - ((exact0 || !active) ? B0 : bj - kBlkGuessBits);
-        uint32_t cnt = 0, sum = 0, dummy_c = 0, dummy_s = 0;
-        blk_parse<kBlkSkip>(W, k, active && !exact0, Qp, C - bj, dummy_c, dummy_s, 0u, nullptr);
-        if (exact0 || !active) Qp = C - B0;
-        uint32_t f = C - Qp;  // first code that starts in my segment
-        blk_parse<kBlkCount>(W, k, active, Qp, C - lim, cnt, sum, 0u, nullptr);
-        if (!active) { cnt = 0; sum = 0; }
-        uint32_t e = C - Qp;  // first code that starts behind it
-
-        // every lane must start where its predecessor ended; lanes that do not, start again from there
-        auto settle = [&]() __attribute__((always_inline)) {
-            for (uint32_t it = 0; it <= (uint32_t)NT; ++it) {
-                s_e[tid] = e;
-                __syncthreads();
-                const uint32_t want = tid ? s_e[tid - 1u] : f;
-                const bool changed = active && want != f;
-                if (!__syncthreads_or(changed ? 1 : 0)) break;  // (also: every read of s_e is done before the next write)
-                if (changed) { f = want; Qp = C - f; cnt = 0; sum = 0; }
-                blk_parse<kBlkCount>(W, k, changed, Qp, C - lim, cnt, sum, 0u, nullptr);
-                if (changed) e = C - Qp;
-            }
-        };
-        settle();
-        const uint32_t last_active = (avail + (uint32_t)kBlkSegW - 1u) / (uint32_t)kBlkSegW - 1u;
-        const uint32_t e_last0 = s_e[last_active];
-        // the end of this block = the start of the next one, published as soon as it is known
-        if (tid == 0) __hip_atomic_store(ends + unit, 0x80000000u | (e_last0 - bend), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (blk > 0) {
+        RunRef nxt = cur;
+        uint32_t next_unit = 0xffffffffu;
+        if (blk_lo >= blk_hi) {  // an empty run (a waveform with fewer blocks than the longest): only the hand-over
             if (tid == 0) {
-                uint32_t v = 0, spins = 0;
-                for (;;) {
-                    v = __hip_atomic_load(ends + unit - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (v & 0x80000000u) break;
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > (1u << 24)) { atomicOr(&st->err, kErrInternal); break; }  // cannot happen; never hang
-                }
-                s_pred = v & 0xffffu;
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(next_ticket)::"memory");
+                s_next = next_ticket;
             }
-            __syncthreads();
-            const uint32_t true_f0 = B0 + s_pred;
-            const bool fix0 = tid == 0 && true_f0 != f;
-            if (__syncthreads_or(fix0 ? 1 : 0)) {
-                if (fix0) { f = true_f0; Qp = C - f; cnt = 0; sum = 0; }
-                blk_parse<kBlkCount>(W, k, fix0, Qp, C - lim, cnt, sum, 0u, nullptr);
-                if (fix0) e = C - Qp;
-                settle();
-                // my successor has started from the end I published: if that end moved, its block is wrong
-                if (tid == 0 && s_e[last_active] != e_last0 && blk + 1u < n_blocks) atomicExch(fail + g, 1u);
-            }
+            blk_barrier();
+            next_unit = s_next;
+            blk_barrier();
+            if (next_unit < total_units) { nxt = run_of(next_unit); if (nxt.blk_lo < nxt.blk_hi) fetch_image(nxt, nxt.blk_lo, img); }
         }
+        uint64_t run_base_c = 0;   // samples in front of the current block (known from the run's second block on)
+        uint32_t run_acc = 0;      // the running sum there
+        uint32_t carry_rel = 0;    // where the previous block's last code ended, in bits behind that block
+        for (uint32_t blk = blk_lo; blk < blk_hi; ++blk) {
+            const bool first_of_run = blk == blk_lo;
+            const uint32_t sidx = (uint32_t)g * slots_per_wave + blk;  // this block's look-back entry and end word
+            const uint32_t w0 = blk * BG::kWords;
+            const uint32_t avail = (n - w0 < BG::kWords) ? n - w0 : BG::kWords;
+            const uint32_t s_i0 = (uint32_t)((int64_t)(pay_lo + w0) - image_base(pay_lo, blk));  // image index of the block's first word
+            store_image(cur, blk, img);
+            blk_barrier();
+            BLK_STAMP(1);  // image
 
-        // ---- samples and residual sum in front of my segment (workgroup scan) and in front of the block (look-back) ----
-        const uint32_t incl_c = wave_incl_scan_dpp(cnt), incl_s = wave_incl_scan_dpp(sum);
-        if (lane == 63) { s_tot[0][wv] = incl_c; s_tot[1][wv] = incl_s; }
-        __syncthreads();
-        uint32_t pre_c = 0, pre_s = 0, tot_c = 0, tot_s = 0;
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const uint32_t tc = s_tot[0][i], ts = s_tot[1][i];
-            if (i < wv) { pre_c += tc; pre_s += ts; }
-            tot_c += tc;
-            tot_s += ts;
-        }
-        if (wv == 0) {
-            const uint64_t mine = ((uint64_t)tot_c << 16) | (uint64_t)(tot_s & 0xffffu);
-            uint64_t ex_c = 0, ex_s = 0;
-            if (blk == 0) {
-                if (lane == 0) __hip_atomic_store(state + unit, kScanPrefix | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                if (lane == 0) __hip_atomic_store(state + unit, kScanAgg | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int64_t first = (int64_t)unit - (int64_t)blk;  // block 0 of this waveform
-                int64_t base = (int64_t)unit - 1;
-                uint32_t spins = 0;
-                for (;;) {
-                    const int64_t i0 = base - lane;
-                    uint64_t sv = kScanPrefix;  // in front of block 0: an empty prefix
-                    if (i0 >= first) sv = __hip_atomic_load(state + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const uint32_t stt = (uint32_t)(sv >> 62);
-                    const uint64_t pm = __ballot(stt == 2u), zm = __ballot(stt == 0u);
-                    const int fp = pm ? __builtin_ctzll(pm) : 64;
-                    const uint64_t nearer = fp >= 64 ? ~0ull : ((1ull << fp) - 1ull);
-                    if (zm & nearer) {
-                        __builtin_amdgcn_s_sleep(1);
-                        if (++spins > (1u << 22)) { if (lane == 0) atomicOr(&st->err, kErrInternal); break; }
-                        continue;
+            // ---- phase 1: where the codes of my segment start, how many there are, what they sum to ----
+            const uint32_t B0 = 32u * s_i0, bend = B0 + 32u * avail;
+            const uint32_t bj = B0 + kSegBits * tid;
+            const bool active = bj < bend;
+            const uint32_t lim = (bj + kSegBits < bend) ? bj + kSegBits : bend;
+            // lane 0 knows its start when the block is the waveform's first (bit 0) or follows one of this run
+            const bool exact0 = tid == 0 && (blk == 0 || !first_of_run);
+            const uint32_t start0 = B0 + (first_of_run ? 0u : carry_rel);
+            uint32_t Qp = C - (exact0 ? start0 : (active ? bj - kBlkGuessBits : B0));
+            uint32_t cnt = 0, sum = 0, dummy_c = 0, dummy_s = 0;
+            blk_parse<kBlkSkip>(W, k, active && !exact0, Qp, C - bj, dummy_c, dummy_s, 0u, nullptr);
+            if (!active) Qp = C - B0;
+            uint32_t f = C - Qp;  // first code that starts in my segment
+            uint32_t *const my_stage = stage + tid * kBlkLaneStride;
+            blk_parse<kBlkCount>(W, k, active, Qp, C - lim, cnt, sum, 0u, nullptr, my_stage);
+            if (!active) { cnt = 0; sum = 0; }
+            uint32_t e = C - Qp;  // first code that starts behind it (or where the padding starts)
+            BLK_STAMP(2);  // run-up + count (thread 0's wave)
+
+            // every lane must start where its predecessor ended; lanes that do not, start again from there
+            auto settle = [&]() __attribute__((always_inline)) {
+                for (uint32_t it = 0; it <= (uint32_t)NT; ++it) {
+                    s_e[tid] = e;
+                    blk_barrier();
+                    const uint32_t want = tid ? s_e[tid - 1u] : f;
+                    const bool changed = active && want != f;
+                    if (!wg_any(changed)) break;  // (also: every read of s_e is done before the next write)
+                    if (changed) { f = want; Qp = C - f; cnt = 0; sum = 0; }
+                    blk_parse<kBlkCount>(W, k, changed, Qp, C - lim, cnt, sum, 0u, nullptr, my_stage);
+                    if (changed) e = C - Qp;
+                }
+            };
+            settle();
+            BLK_STAMP(3);  // settle (includes waiting for the slowest wave)
+            const uint32_t last_active = (avail + (uint32_t)kBlkSegW - 1u) / (uint32_t)kBlkSegW - 1u;
+            const uint32_t e_last0 = s_e[last_active];
+            const bool last_of_run = blk + 1u == blk_hi;
+            // the end of this run = the start of the next one, published as soon as it is known
+            if (tid == 0 && last_of_run)
+                __hip_atomic_store(ends + sidx, 0x80000000u | (e_last0 - bend), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (first_of_run && blk > 0) {
+                if (tid == 0) {
+                    uint32_t v = 0, spins = 0;
+                    for (;;) {
+                        v = __hip_atomic_load(ends + sidx - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (v & 0x80000000u) break;
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > (1u << 24)) { atomicOr(&st->err, kErrInternal); break; }  // cannot happen; never hang
                     }
-                    const uint64_t val = (lane <= fp) ? (sv & kScanValMask) : 0ull;
-                    ex_c += wave_sum_u64(val >> 16);
-                    ex_s += wave_sum_u64(val & 0xffffull);
-                    if (fp < 64) break;
-                    base -= 64;
+                    s_pred = v & 0xffffu;
                 }
-                if (lane == 0)
-                    __hip_atomic_store(state + unit, kScanPrefix | ((((ex_c + tot_c) << 16) | ((ex_s + tot_s) & 0xffffull)) & kScanValMask),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                blk_barrier();
+                const uint32_t true_f0 = B0 + s_pred;
+                const bool fix0 = tid == 0 && true_f0 != f;
+                if (wg_any(fix0)) {
+                    if (fix0) { f = true_f0; Qp = C - f; cnt = 0; sum = 0; }
+                    blk_parse<kBlkCount>(W, k, fix0, Qp, C - lim, cnt, sum, 0u, nullptr, my_stage);
+                    if (fix0) e = C - Qp;
+                    settle();
+                    // a one-block run has published its end already, and its successor has started from it: if that end
+                    // moved, the successor's run is wrong
+                    if (tid == 0 && last_of_run && s_e[last_active] != e_last0 && blk + 1u < n_blocks) atomicExch(fail + g, 1u);
+                }
             }
-            if (lane == 0) { s_b[0] = ex_c; s_b[1] = ex_s; }
-        }
-        __syncthreads();
-        const uint64_t base_c = s_b[0];
-        const uint32_t acc_base = (uint32_t)s_b[1];
-        // the waveform has `len` samples; a code decoded out of the zero padding behind the last one does not count
-        const uint32_t blk_first = base_c < (uint64_t)len ? (uint32_t)base_c : len;
-        const uint32_t blk_count = (tot_c < len - blk_first) ? tot_c : len - blk_first;
-        const uint32_t rel0 = pre_c + incl_c - cnt;  // my first sample, relative to the block's first
-        const uint32_t todo = rel0 >= blk_count ? 0u : ((cnt < blk_count - rel0) ? cnt : blk_count - rel0);
-        // the stream ended before the waveform did: a verdict for the kernel that runs after this one (a block behind a
-        // mis-started one counts garbage, and its waveform is flagged for the fallback anyway)
-        if (tid == 0 && blk + 1u == n_blocks && base_c + tot_c < (uint64_t)len) atomicExch(suspect + g, 1u);
+            const uint32_t e_end = s_e[last_active];  // (after a correction: the corrected end)
+            BLK_STAMP(4);  // predecessor's end
 
-        // ---- phase 2: the samples, staged in output order, whole lines to HBM ----
-        uint32_t c = 0, acc = acc_base + pre_s + incl_s - sum;
-        Qp = C - (todo ? f : B0);
-        const uint32_t a0 = (uint32_t)((((uintptr_t)(y + blk_first)) >> 1) & 7u);  // kOutCap is a multiple of 8: the same every pass
-        for (uint32_t R0 = 0; R0 < blk_count; R0 += BG::kOutCap) {
-            // my samples with block-relative index below R0 + kOutCap
-            const uint32_t cmax = (rel0 >= R0 + BG::kOutCap) ? 0u : ((todo < R0 + BG::kOutCap - rel0) ? todo : R0 + BG::kOutCap - rel0);
-            // slot of sample c: a0 + rel0 + c - R0 (>= a0 for every c this pass decodes)
-            uint16_t *outp = obuf + (int32_t)(a0 + rel0 - R0);
-            blk_parse<kBlkValue>(W, k, c < cmax, Qp, 0u, c, acc, cmax, outp);
-            __syncthreads();
-            const uint32_t nsamp = (blk_count - R0 < BG::kOutCap) ? blk_count - R0 : BG::kOutCap;
-            g_u16 *gbase = (g_u16 *)(y + blk_first + R0) - a0;  // 16-byte aligned
-            const uint32_t np = (a0 + nsamp + 7u) >> 3;
-            for (uint32_t p = tid; p < np; p += NT) {
-                const uint32_t s_lo = 8u * p;
-                if (s_lo >= a0 && s_lo + 8u <= a0 + nsamp) {
-                    const uint4 v = *reinterpret_cast<const uint4 *>(obuf + s_lo);
-                    *(g_uint4 *)(gbase + s_lo) = (u32x4v){v.x, v.y, v.z, v.w};
-                } else {
+            // ---- samples and residual sum in front of my segment (workgroup scan) and in front of the block ----
+            const uint32_t incl_c = wave_incl_scan_dpp(cnt), incl_s = wave_incl_scan_dpp(sum);
+            if (lane == 63) { s_tot[0][wv] = incl_c; s_tot[1][wv] = incl_s; }
+            if (tid == 0 && last_of_run) {  // (drawn at the start of the run: it has arrived)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(next_ticket)::"memory");
+                s_next = next_ticket;
+            }
+            blk_barrier();
+            uint32_t pre_c = 0, pre_s = 0, tot_c = 0, tot_s = 0;
 #pragma unroll
-                    for (uint32_t j = 0; j < 8u; ++j)
-                        if (s_lo + j >= a0 && s_lo + j < a0 + nsamp) gbase[s_lo + j] = obuf[s_lo + j];
+            for (int i = 0; i < NW; ++i) {
+                const uint32_t tc = s_tot[0][i], ts = s_tot[1][i];
+                if (i < wv) { pre_c += tc; pre_s += ts; }
+                tot_c += tc;
+                tot_s += ts;
+            }
+            if (wv == 0) {
+                const uint64_t mine = ((uint64_t)tot_c << 16) | (uint64_t)(tot_s & 0xffffu);
+                uint64_t ex_c = run_base_c, ex_s = run_acc;
+                if (blk == 0) {
+                    ex_c = 0;
+                    ex_s = 0;
+                } else if (first_of_run) {
+                    // decoupled look-back over the blocks of the waveform in front of this one
+                    ex_c = 0;
+                    ex_s = 0;
+                    if (lane == 0) __hip_atomic_store(state + sidx, kScanAgg | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int64_t first = (int64_t)sidx - (int64_t)blk;  // block 0 of this waveform
+                    int64_t base = (int64_t)sidx - 1;
+                    uint32_t spins = 0;
+                    for (;;) {
+                        // lane l looks at predecessors base - l (nearer) and base - 64 - l (farther)
+                        const int64_t i0 = base - lane, i1 = base - 64 - lane;
+                        uint64_t s0v = kScanPrefix, s1v = kScanPrefix;  // in front of block 0: an empty prefix
+                        if (i0 >= first) s0v = __hip_atomic_load(state + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (i1 >= first) s1v = __hip_atomic_load(state + i1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint32_t st0 = (uint32_t)(s0v >> 62), st1 = (uint32_t)(s1v >> 62);
+                        const uint64_t p0 = __ballot(st0 == 2u), z0 = __ballot(st0 == 0u);
+                        const uint64_t p1 = __ballot(st1 == 2u), z1 = __ballot(st1 == 0u);
+                        const int fp = p0 ? __builtin_ctzll(p0) : (p1 ? 64 + __builtin_ctzll(p1) : 128);  // nearest prefix
+                        const uint64_t near0 = fp >= 64 ? ~0ull : ((1ull << fp) - 1ull);
+                        const uint64_t near1 = fp >= 128 ? ~0ull : (fp > 64 ? ((1ull << (fp - 64)) - 1ull) : 0ull);
+                        if ((z0 & near0) | (z1 & near1)) {  // a nearer predecessor has not published yet
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++spins > (1u << 22)) { if (lane == 0) atomicOr(&st->err, kErrInternal); break; }
+                            continue;
+                        }
+                        const uint64_t v0 = (lane <= fp) ? (s0v & kScanValMask) : 0ull;
+                        const uint64_t v1 = (64 + lane <= fp) ? (s1v & kScanValMask) : 0ull;
+                        ex_c += wave_sum_u64((v0 >> 16) + (v1 >> 16));
+                        ex_s += wave_sum_u64((v0 & 0xffffull) + (v1 & 0xffffull));
+                        if (fp < 128) break;
+                        base -= 128;
+                    }
+                }
+                // everything in front of this block is known now: its successors find a prefix here
+                if (lane == 0)
+                    __hip_atomic_store(state + sidx, kScanPrefix | ((((ex_c + tot_c) << 16) | ((ex_s + tot_s) & 0xffffull)) & kScanValMask),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) { s_b[0] = ex_c; s_b[1] = ex_s; }
+            }
+            blk_barrier();
+            BLK_STAMP(5);  // scan + look-back
+            const uint64_t base_c = s_b[0];
+            const uint32_t acc_base = (uint32_t)s_b[1];
+            run_base_c = base_c + tot_c;
+            run_acc = acc_base + tot_s;
+            carry_rel = e_end - bend;
+            // The next block's image -- of this run or of the next ticket's -- travels while this one's samples are put in
+            // order and written out.  (Issued earlier -- at the top of the block, or behind the count -- the loads were
+            // measured no faster to arrive: the wait in front of the next block is for this block's output lines, whose
+            // store loop the compiler cannot count, and retiring the loads by hand in front of those stores only moved the
+            // wait there: profiles/r02_notes.md.)
+            if (!last_of_run) {
+                fetch_image(cur, blk + 1u, img);
+            } else {
+                next_unit = s_next;
+                if (next_unit < total_units) { nxt = run_of(next_unit); if (nxt.blk_lo < nxt.blk_hi) fetch_image(nxt, nxt.blk_lo, img); }
+            }
+            // the waveform has `len` samples; a code decoded out of the zero padding behind the last one does not count
+            const uint32_t blk_first = base_c < (uint64_t)len ? (uint32_t)base_c : len;
+            const uint32_t blk_count = (tot_c < len - blk_first) ? tot_c : len - blk_first;
+            const uint32_t rel0 = pre_c + incl_c - cnt;  // my first sample, relative to the block's first
+            const uint32_t todo = rel0 >= blk_count ? 0u : ((cnt < blk_count - rel0) ? cnt : blk_count - rel0);
+            // Verdicts, left to the kernel that runs after this one (a block behind a mis-started one counts garbage, and its
+            // waveform is flagged for the fallback anyway): the waveform's last block must bring the count to exactly `len`
+            // samples, and its last code must end in the last payload word: n_i = ceil(bits / 32) (src/deltaRice.c:237-241).
+            if (tid == 0 && blk + 1u == n_blocks) {
+                if (base_c + tot_c != (uint64_t)len || w0 + ((e_end - B0 + 31u) >> 5) != n) atomicExch(suspect + g, 1u);
+            }
+
+            // ---- phase 2: the samples in output order, whole lines to HBM ----
+            const uint32_t a0 = (uint32_t)((((uintptr_t)(y + blk_first)) >> 1) & 7u);  // kOutCap is a multiple of 8: the same every pass
+            auto copy_out = [&](uint32_t R0) __attribute__((always_inline)) {  // staged samples [R0, R0 + kOutCap) of the block -> HBM
+                const uint32_t nsamp = (blk_count - R0 < BG::kOutCap) ? blk_count - R0 : BG::kOutCap;
+                g_u16 *gbase = (g_u16 *)(y + blk_first + R0) - a0;  // 16-byte aligned
+                const uint32_t np = (a0 + nsamp + 7u) >> 3;
+                for (uint32_t p = tid; p < np; p += NT) {
+                    const uint32_t s_lo = 8u * p;
+                    if (s_lo >= a0 && s_lo + 8u <= a0 + nsamp) {
+                        const uint4 v = *reinterpret_cast<const uint4 *>(obuf + s_lo);
+                        *(g_uint4 *)(gbase + s_lo) = (u32x4v){v.x, v.y, v.z, v.w};
+                    } else {
+#pragma unroll
+                        for (uint32_t j = 0; j < 8u; ++j)
+                            if (s_lo + j >= a0 && s_lo + j < a0 + nsamp) gbase[s_lo + j] = obuf[s_lo + j];
+                    }
+                }
+            };
+            // the common case: every lane's codes are all samples of the waveform and fit its share of the staging buffer
+            const bool lane_ok = cnt <= kBlkLaneCap && todo == cnt;
+            if (!wg_any(!lane_ok)) {
+                constexpr int NR = (int)(kBlkLaneCap / 2u);
+                uint32_t rr[NR];
+#pragma unroll
+                for (int i = 0; i < NR; ++i) rr[i] = my_stage[i];
+                blk_barrier();  // every lane holds its samples: the buffer may now be rewritten in output order
+                const uint32_t base16 = (acc_base + pre_s + incl_s - sum) & 0xffffu;  // the running sum in front of my first sample
+                const uint32_t slot0 = a0 + rel0, dump = 2u * BG::kStageWords - 1u;  // (the last halfword: beyond a0 + kOutCap)
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    obuf[(2u * (uint32_t)i < cnt) ? slot0 + 2u * (uint32_t)i : dump] = (uint16_t)(rr[i] + base16);
+                    obuf[(2u * (uint32_t)i + 1u < cnt) ? slot0 + 2u * (uint32_t)i + 1u : dump] = (uint16_t)((rr[i] >> 16) + base16);
+                }
+                blk_barrier();
+                BLK_STAMP(6);  // reorder
+                copy_out(0u);
+                BLK_STAMP(7);  // copy-out
+            } else {
+                // some lane holds more codes than its share (long runs of tiny residuals), or codes past the waveform's
+                // last sample (a corrupt stream): decode again from f, in as many staging passes as the block needs
+                uint32_t c = 0, acc = acc_base + pre_s + incl_s - sum;
+                Qp = C - (todo ? f : B0);
+                for (uint32_t R0 = 0; R0 < blk_count; R0 += BG::kOutCap) {
+                    // my samples with block-relative index below R0 + kOutCap
+                    const uint32_t cmax = (rel0 >= R0 + BG::kOutCap) ? 0u : ((todo < R0 + BG::kOutCap - rel0) ? todo : R0 + BG::kOutCap - rel0);
+                    // slot of sample c: a0 + rel0 + c - R0 (>= a0 for every c this pass decodes)
+                    uint16_t *outp = obuf + (int32_t)(a0 + rel0 - R0);
+                    blk_parse<kBlkValue>(W, k, c < cmax, Qp, 0u, c, acc, cmax, outp);
+                    blk_barrier();
+                    copy_out(R0);
+                    blk_barrier();
                 }
             }
-            __syncthreads();
+            blk_barrier();  // W, the staging buffer and the s_* words are rewritten by the next block
+            BLK_STAMP(8);
         }
-        // the waveform's last code must end in its last payload word: n_i = ceil(bits / 32) (src/deltaRice.c:237-241)
-        if (todo && c == todo && (uint64_t)blk_first + rel0 + todo == (uint64_t)len) {
-            const uint32_t bits_in_block = (C - Qp) - B0;
-            if (w0 + ((bits_in_block + 31u) >> 5) != n) atomicExch(suspect + g, 1u);
-        }
-        __syncthreads();  // W, obuf and the s_* words are rewritten by the next unit
+        if (next_unit >= total_units) return;
+        unit = next_unit;
+        cur = nxt;
     }
 }
 
@@ -386,35 +585,40 @@ bool blocks_batch(const Geom &G) {
 
 static int blocks_nt(const Geom &G) {
     // lanes per block: a waveform of about (k + 3.5) bits per sample should fill most of its last block
+#ifdef DRX_BLK_FORCE_NT
+    return DRX_BLK_FORCE_NT;
+#endif
     const uint64_t typ_words = ((uint64_t)G.u_wave_len * (2u * G.k + 7u)) >> 6;
     return typ_words <= blk_words(64) ? 64 : (typ_words <= blk_words(128) ? 128 : 256);
 }
 
-static uint64_t blocks_units_max(const Geom &G) {
+static uint32_t blocks_slots_per_wave(const Geom &G) {  // blocks of a waveform at 25 bits per sample
     const uint64_t per = (max_payload_words(G.u_wave_len) + blk_words(blocks_nt(G)) - 1u) / blk_words(blocks_nt(G));
-    return G.total_waves * (per ? per : 1u);
+    return (uint32_t)(per ? per : 1u);
 }
 
-// scratch: u32 unit_first[W + 1] | u32 fail[W] | u32 suspect[W] | u32 ticket[1] (+ pad to 8 bytes) | u32 ends[units] | u64 state[units]
+// scratch: u32 info[4] | u32 fail[W] | u32 suspect[W] | u32 ticket[1] (+ pad to 16 bytes) | u32 ends[slots] | u64 state[slots] | prof
 struct BlkScratch {
-    uint32_t *unit_first, *fail, *suspect, *ticket, *ends;
+    uint32_t *info, *fail, *suspect, *ticket, *ends;
     uint64_t *state;
+    unsigned long long *prof;  // 16 counters of the diagnostic build
     uint64_t bytes;
 };
 static BlkScratch blocks_layout(const Geom &G, void *base) {
-    const uint64_t W = G.total_waves, U = blocks_units_max(G);
-    uint64_t n32 = (W + 1u) + W + W + 1u;
+    const uint64_t W = G.total_waves, U = W * blocks_slots_per_wave(G);
+    uint64_t n32 = 4u + W + W + 1u;
     n32 = (n32 + 3u) & ~3ull;
     BlkScratch L;
     uint32_t *p = reinterpret_cast<uint32_t *>(base);
-    L.unit_first = p;
-    L.fail = p + (W + 1u);
+    L.info = p;
+    L.fail = p + 4u;
     L.suspect = L.fail + W;
     L.ticket = L.suspect + W;
     L.ends = p + n32;
     const uint64_t ends32 = (U + 1u) & ~1ull;
     L.state = reinterpret_cast<uint64_t *>(L.ends + ends32);
-    L.bytes = (n32 + ends32) * 4u + U * 8u;
+    L.prof = reinterpret_cast<unsigned long long *>(L.state + U);
+    L.bytes = (n32 + ends32) * 4u + U * 8u + 16u * 8u;
     return L;
 }
 
@@ -427,22 +631,38 @@ hipError_t launch_decode_blocks(const Geom &G, const uint32_t *d_in, uint64_t in
     hipError_t e = hipMemsetAsync(d_blk, 0, L.bytes, s);
     if (e != hipSuccess) return e;
     const int nt = blocks_nt(G);
-    k_blk_units<<<1, 1024, 0, s>>>(G.total_waves, d_wave_words, blk_words((uint32_t)nt), L.unit_first);
+    k_blk_max<<<1, 1024, 0, s>>>(G.total_waves, d_wave_words, blk_words((uint32_t)nt), L.info);
     // resident grid: 256 CUs x workgroups per CU (LDS: 51 KB at NT = 256, 26 KB at 128, 13 KB at 64), never more than there are units
-    const uint64_t units = blocks_units_max(G);
+    const uint32_t spw = blocks_slots_per_wave(G);
+    const uint64_t units = G.total_waves * spw;
+    // runs of several blocks only when two runs of one waveform are never in flight together (see the kernel)
+    const uint32_t run_len = G.total_waves >= 768u ? kBlkRun : 1u;
     if (nt == 64) {
         const unsigned grid = (unsigned)(units < 256u * 12u ? units : 256u * 12u);
-        k_decode_blocks<64><<<grid, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, L.unit_first, L.state, L.ends, L.ticket,
-                                               L.fail, L.suspect, d_status, d_out);
+        k_decode_blocks<64><<<grid, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, L.info, spw, run_len, L.state, L.ends, L.ticket,
+                                               L.fail, L.suspect, d_status, d_out, L.prof);
     } else if (nt == 128) {
         const unsigned grid = (unsigned)(units < 256u * 6u ? units : 256u * 6u);
-        k_decode_blocks<128><<<grid, 128, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, L.unit_first, L.state, L.ends, L.ticket,
-                                                 L.fail, L.suspect, d_status, d_out);
+        k_decode_blocks<128><<<grid, 128, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, L.info, spw, run_len, L.state, L.ends, L.ticket,
+                                                 L.fail, L.suspect, d_status, d_out, L.prof);
     } else {
         const unsigned grid = (unsigned)(units < 256u * 3u ? units : 256u * 3u);
-        k_decode_blocks<256><<<grid, 256, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, L.unit_first, L.state, L.ends, L.ticket,
-                                                 L.fail, L.suspect, d_status, d_out);
+        k_decode_blocks<256><<<grid, 256, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, L.info, spw, run_len, L.state, L.ends, L.ticket,
+                                                 L.fail, L.suspect, d_status, d_out, L.prof);
     }
+#ifdef DRX_BLK_STAMPS
+    {
+        unsigned long long h[16];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, L.prof, sizeof h, hipMemcpyDeviceToHost);
+        static const char *names[9] = {"ticket", "image load", "run-up + count", "settle", "pred end", "scan + look-back", "reorder", "copy-out", "tail"};
+        unsigned long long tot = 0;
+        for (int i = 0; i < 9; ++i) tot += h[i];
+        fprintf(stderr, "[blk stamps]");
+        for (int i = 0; i < 9; ++i) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)h[i] / (double)(tot ? tot : 1));
+        fprintf(stderr, "\n");
+    }
+#endif
     *fail_out = L.fail;
     *suspect_out = L.suspect;
     return hipGetLastError();

@@ -98,13 +98,17 @@ def cpu_baseline(x_host_chunks, opts, budget_s):
     try:
         np.save(path, arr)
         legs = {}
-        for name, th, share in (("all", n_threads, 0.5), ("one", 1, 0.5)):
+        # "all host cores": the box advertises every core of the host, a GPU slot's share of them is far smaller, and the
+        # reference's OpenMP loop over 2000 waveforms collapses when over-subscribed (256 threads: slower than one).
+        # Probe the team sizes the reference publishes numbers for (32) and a slot's share (16), keep the faster one.
+        for name, th, share in (("t16", min(16, n_threads), 0.25), ("t32", min(32, n_threads), 0.25), ("one", 1, 0.5)):
             env = dict(os.environ, OMP_NUM_THREADS=str(th), OMP_PROC_BIND="false")
             r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_time.py"), path, str(opts[0]), str(opts[1]),
                                 str(budget_s * share)], env=env, capture_output=True, text=True, timeout=600)
             if r.returncode != 0:
                 raise RuntimeError("cpu baseline leg failed: " + r.stderr[-2000:])
             legs[name] = json.loads(r.stdout.strip().splitlines()[-1])
+        legs["all"] = max(legs["t16"], legs["t32"], key=lambda d: d["value"])
     finally:
         os.unlink(path)
     a, o = legs["all"], legs["one"]
@@ -115,6 +119,7 @@ def cpu_baseline(x_host_chunks, opts, budget_s):
         "encode_GBps": a["encode_GBps"], "decode_GBps": a["decode_GBps"],
         "one_thread": {"value": o["value"], "encode_GBps": o["encode_GBps"], "decode_GBps": o["decode_GBps"],
                        "cores": o["threads"], "chunks": o["chunks"]},
+        "threads_tried": {str(legs[k]["threads"]): legs[k]["value"] for k in ("t16", "t32")}, "host_cpus": n_threads,
         "sample": f"{a['chunks']} chunks ({a['raw_bytes'] / 1e6:.0f} MB raw) of the bench workload with {a['threads']} threads, "
                   f"{o['chunks']} chunks with 1 thread; {what}; only the filter call is timed",
     }

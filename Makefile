@@ -12,8 +12,9 @@ HIPFLAGS  ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-funct
 CSRC      := deltarice_amd/csrc
 HIP_LIB   := deltarice_amd/libdeltarice_hip.so
 PLUGIN    := deltarice_amd/plugin/libh5deltarice.so
-HIP_SRCS  := $(CSRC)/drx_kernels.hip $(CSRC)/drx_blocks.hip $(CSRC)/drx_api.hip
-HIP_HDRS  := $(CSRC)/drx_internal.h $(CSRC)/drx_device.h include/deltarice_hip.h
+HIP_SRCS  := $(CSRC)/drx_kernels.hip $(CSRC)/drx_blocks.hip $(CSRC)/drx_pieces.hip $(CSRC)/drx_api.hip
+HIP_OBJS  := $(HIP_SRCS:.hip=.o)
+HIP_HDRS  := $(CSRC)/drx_internal.h $(CSRC)/drx_device.h $(CSRC)/drx_encode.h include/deltarice_hip.h
 
 H5IO      := deltarice_amd/libdeltarice_h5io.so
 
@@ -30,8 +31,11 @@ PLUGIN_DIR ?= /usr/local/hdf5/lib/plugin
 all: hip plugin h5io pyext
 
 hip: $(HIP_LIB)
-$(HIP_LIB): $(HIP_SRCS) $(HIP_HDRS)
-	$(HIPCC) $(HIPFLAGS) -shared $(HIP_SRCS) -o $@
+# one object per translation unit (no device code crosses them), so that a change to one kernel file rebuilds that file
+$(CSRC)/%.o: $(CSRC)/%.hip $(HIP_HDRS)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(HIP_LIB): $(HIP_OBJS)
+	$(HIPCC) $(HIPFLAGS) -shared $(HIP_OBJS) -o $@
 
 plugin: $(PLUGIN)
 $(PLUGIN): $(CSRC)/h5z_deltarice.c include/deltarice_h5filter.h include/deltarice_hip.h $(HIP_LIB)
@@ -67,6 +71,6 @@ oracle:
 	$(MAKE) -C oracle all
 
 clean:
-	rm -f $(HIP_LIB) $(PLUGIN) $(H5IO) $(PYEXT)
+	rm -f $(HIP_LIB) $(HIP_OBJS) $(PLUGIN) $(H5IO) $(PYEXT)
 	rm -rf build/pyext
 	$(MAKE) -C oracle clean

@@ -80,6 +80,9 @@ struct drx_plan {
     uint32_t *d_seg_bits = nullptr;    // few long waveforms: bits and bit position of every 8192-sample segment,
     uint64_t *d_seg_pos = nullptr;     // allocated by the first encode that needs them
     uint64_t *d_seg_unit_base = nullptr;  // ragged plans the segment encoder takes
+    uint32_t *d_pc_wg_base = nullptr;     // ragged plans the pieces encoder takes: first workgroup of every chunk
+    uint64_t *d_pc_scan = nullptr;        // pieces encoder: look-back entry per workgroup + ticket
+    uint64_t pc_wgs = 0;                  // its workgroups (0: the plan's geometry never takes it)
     void *d_pw = nullptr;              // a handful of chunks: candidate lists of the parallel header walk
     void *d_blk = nullptr;             // few waveforms: unit table, look-back state and flags of the block-parallel decoder
     uint32_t *d_walk_lists = nullptr;  // ragged plans: chunk indices, short-waveform chunks first
@@ -245,6 +248,8 @@ static void plan_free(drx_plan *p) {
     if (p->d_seg_bits) (void)hipFree(p->d_seg_bits);
     if (p->d_seg_pos) (void)hipFree(p->d_seg_pos);
     if (p->d_seg_unit_base) (void)hipFree(p->d_seg_unit_base);
+    if (p->d_pc_wg_base) (void)hipFree(p->d_pc_wg_base);
+    if (p->d_pc_scan) (void)hipFree(p->d_pc_scan);
     if (p->d_pw) (void)hipFree(p->d_pw);
     if (p->d_blk) (void)hipFree(p->d_blk);
     if (p->d_status) (void)hipFree(p->d_status);
@@ -278,6 +283,12 @@ static drx_status plan_alloc_scratch(drx_ctx *ctx, drx_plan *p) {
     }
     if (const uint64_t nb = par_walk_scratch_bytes(p->G)) DRX_HIP(ctx, hipMalloc(&p->d_pw, nb));
     if (const uint64_t nb = blocks_scratch_bytes(p->G)) DRX_HIP(ctx, hipMalloc(&p->d_blk, nb));
+    if (p->G.uniform) {  // the pieces encoder's workgroups, where the geometry is one it can take (pieces_batch() decides per call)
+        const uint32_t L = p->G.u_wave_len;
+        const uint64_t wgs = (uint64_t)piece_shape(L, p->G.u_n_waves).wgs * p->G.n_chunks;
+        if (L >= kPcMinLen && L <= kPcMaxLen && wgs <= 0x7fffffffull && p->total_samples >= 512u) p->pc_wgs = wgs;
+    }
+    if (p->pc_wgs) DRX_HIP(ctx, hipMalloc((void **)&p->d_pc_scan, (p->pc_wgs + 2) * sizeof(uint64_t)));
     return DRX_OK;
 }
 
@@ -382,6 +393,27 @@ drx_status drx_plan_create(drx_ctx *ctx, uint64_t n_chunks, const uint32_t *chun
             p->G.seg_unit_base = p->d_seg_unit_base;
             p->G.seg_units = ub[n_chunks];
         }
+        // the pieces encoder (drx_pieces.hip): every WaveformLength within its range and some chunk of short or of
+        // long waveforms; workgroup numbering per chunk
+        {
+            bool ok = soff >= 512u, some = false;
+            std::vector<uint32_t> wb(n_chunks + 1, 0);
+            uint64_t wgs = 0;
+            for (uint64_t c = 0; c < n_chunks && ok; ++c) {
+                ok = desc[c].wave_len >= kPcMinLen && desc[c].wave_len <= kPcMaxLen;
+                const PieceShape sh = piece_shape(desc[c].wave_len, desc[c].n_waves);
+                some = some || sh.run > 1u || sh.segs > 1u;
+                wgs += sh.wgs;
+                ok = ok && wgs <= 0x7fffffffull;
+                wb[c + 1] = (uint32_t)wgs;
+            }
+            if (ok && some) {
+                if (e == hipSuccess) e = hipMalloc((void **)&p->d_pc_wg_base, wb.size() * sizeof(uint32_t));
+                if (e == hipSuccess) e = hipMemcpy(p->d_pc_wg_base, wb.data(), wb.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+                p->G.pc_wg_base = p->d_pc_wg_base;
+                p->pc_wgs = wgs;
+            }
+        }
         if (e != hipSuccess) st = fail(ctx, DRX_ERR_DEVICE, "chunk table upload failed: %s", hipGetErrorString(e));
     }
     if (st != DRX_OK) { plan_free(p); return st; }
@@ -475,7 +507,10 @@ drx_status drx_encode(drx_plan *p, const int16_t *d_in, uint32_t *d_out, uint64_
     DRX_ON_DEVICE(ctx);
     DRX_HIP(ctx, hipMemsetAsync(p->d_status, 0, sizeof(DevStatus), ctx->stream));
     p->G.dbg = ctx->debug_flags;
-    if (ctx->encode_impl == 1 && long_batch(p->G) && !(ctx->debug_flags & 256u)) {
+    if (ctx->encode_impl == 1 && p->d_pc_scan && pieces_batch(p->G)) {
+        DRX_HIP(ctx, launch_encode_pieces(p->G, d_in, p->total_samples, d_out, out_cap_words, d_chunk_word_off, p->d_wave_words,
+                                          p->d_pc_scan, p->pc_wgs, p->d_status, ctx->profile ? p->ev : nullptr, ctx->stream));
+    } else if (ctx->encode_impl == 1 && long_batch(p->G) && !(ctx->debug_flags & 256u)) {
         if (!p->d_seg_bits) {  // only when a diagnostic debug_flags value forces this path on a geometry that does not take it
             const uint64_t units = long_batch_units(p->G);
             DRX_HIP(ctx, hipMalloc((void **)&p->d_seg_bits, units * sizeof(uint32_t)));

@@ -41,6 +41,7 @@ struct Geom {
                    // forced path is bit-exact and the tests use them to reach it):
                    //   256 never take the long-waveform paths   512 long waveforms: one workgroup per waveform only
                    //  2048 never take the parallel header walks of small batches   8192 always the segment encoder
+                   //  4096 never the pieces encoder   32768 the pieces encoder wherever its geometry allows
                    // Ablation switches INSIDE the kernels, compiled only with -DDRX_ABLATION (results invalid):
                    //   decode:   1 skip the output stores   2 skip the stream loads
                    //             4 request pieces without counting on the round's minimum consumption   16384 long: no stores
@@ -61,6 +62,8 @@ struct Geom {
     // wavefront, longest WaveformLength first; rag_groups entries
     const uint2 *rag_order;
     uint32_t rag_groups;
+    // ragged batches the pieces encoder takes (drx_pieces.hip): first workgroup of every chunk, n_chunks + 1 entries
+    const uint32_t *pc_wg_base;
 };
 
 struct DevStatus {
@@ -101,6 +104,44 @@ uint64_t blocks_scratch_bytes(const Geom &G);
 hipError_t launch_decode_blocks(const Geom &G, const uint32_t *d_in, uint64_t in_words, const uint64_t *d_wave_off,
                                 const uint32_t *d_wave_words, void *d_blk, DevStatus *d_status, int16_t *d_out,
                                 const uint32_t **fail_out, const uint32_t **suspect_out, hipStream_t s);
+// single-pass encoder for short and long waveforms (drx_pieces.hip): a wavefront takes a PIECE, either a run of whole
+// short waveforms or one segment of a long one; the pieces of a chunk fill whole workgroups of kPcWaves wavefronts
+constexpr uint32_t kPcWaves = 8;
+constexpr uint32_t kPcRunSamples = 7168;  // samples of a run of short waveforms (9.1 bits per sample fit the LDS buffer)
+constexpr uint32_t kPcMaxRun = 16;        // waveforms of a run
+constexpr uint32_t kPcSegSamples = 8192;  // most samples of a segment
+constexpr uint32_t kPcWholeLen = 10240;   // WaveformLengths up to here stay whole (6.4 bits per sample fit the buffer)
+constexpr uint32_t kPcMinLen = 64, kPcMaxLen = kPcSegSamples * kPcWaves;  // WaveformLengths it takes
+struct PieceShape {
+    uint32_t run;      // waveforms per piece (> 1: runs of short waveforms)
+    uint32_t segs;     // pieces per waveform (a power of two <= kPcWaves; > 1: long waveforms)
+    uint32_t seg_len;  // samples per segment (a multiple of 512)
+    uint32_t pieces;   // of the chunk
+    uint32_t wgs;      // workgroups of the chunk
+};
+__host__ __device__ inline PieceShape piece_shape(uint32_t L, uint32_t W) {
+    PieceShape s;
+    if (L <= kPcRunSamples / 2u) {
+        s.run = kPcRunSamples / L < kPcMaxRun ? kPcRunSamples / L : kPcMaxRun;
+        s.segs = 1u;
+        s.seg_len = L;
+        s.pieces = (W + s.run - 1u) / s.run;
+    } else {
+        const uint32_t need = L <= kPcWholeLen ? 1u : (L + kPcSegSamples - 1u) / kPcSegSamples;
+        s.run = 1u;
+        s.segs = 1u;
+        while (s.segs < need) s.segs <<= 1;
+        s.seg_len = s.segs == 1u ? L : ((((L + s.segs - 1u) / s.segs) + 511u) & ~511u);
+        s.pieces = W * s.segs;
+    }
+    s.wgs = (s.pieces + kPcWaves - 1u) / kPcWaves;
+    return s;
+}
+bool pieces_batch(const Geom &G);       // the batch takes this encoder
+uint64_t pieces_workgroups(const Geom &G, const ChunkDesc *host_chunks);
+hipError_t launch_encode_pieces(const Geom &G, const int16_t *d_in, uint64_t in_samples, uint32_t *d_out, uint64_t out_cap,
+                                uint64_t *d_chunk_word_off, uint32_t *d_wave_words, uint64_t *d_scan, uint64_t total_wgs,
+                                DevStatus *d_status, hipEvent_t *ev, hipStream_t s);
 uint64_t par_walk_scratch_bytes(const Geom &G);
 uint32_t bw_walk_blocks_max(const Geom &G);
 constexpr uint32_t kWalkShortLenHost = 2048;  // keep equal to kWalkShortLen in drx_kernels.hip

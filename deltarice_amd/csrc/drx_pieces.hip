@@ -1,0 +1,454 @@
+// drx_pieces.hip -- single-pass encoder for batches whose waveforms are much shorter or much longer than the
+// ~2000-8000 samples one wavefront of k_encode_fused (drx_kernels.hip) likes (gfx950).
+//
+// k_encode_fused gives a waveform to a wavefront: with WaveformLength 512 it pays a workgroup barrier, a share of a
+// look-back and an 8 KB LDS clear per 512 samples, and beyond ~10 000 samples the code outgrows the wavefront's LDS
+// buffer and the waveform is encoded twice.  Those batches went to the two-pass segment encoder (sizes, scan, pack: every
+// sample read and coded twice).  Here the unit a wavefront takes is a PIECE of a chunk:
+//   run      WaveformLength <= 3584: kPcRunSamples / L consecutive whole waveforms.  Their streams are word aligned and
+//            follow one another in the encoded chunk (src/deltaRice.c:427-433), so the wavefront builds
+//            [n_0 | payload_0 | n_1 | payload_1 | ...] in its LDS buffer and copies it out in one piece;
+//   segment  WaveformLength > 10 240: the waveform is cut into 2, 4 or 8 segments of whole tiles, one wavefront each, all in
+//            ONE workgroup.  A segment is coded from bit 0 of its wavefront's buffer; once the workgroup knows the bits
+//            of every segment, segment s is copied out shifted to its bit position inside the waveform's stream, the word
+//            it shares with segment s + 1 completed from that wavefront's buffer (LDS, no global atomics, no zeroing);
+//   else     one waveform, as k_encode_fused.
+// The pieces of a chunk fill whole workgroups (a workgroup never spans two chunks), one ticket and one look-back entry
+// per workgroup as in k_encode_fused.  A piece whose code outgrows the 8 KB buffer (incompressible data) is coded again
+// after the look-back, tile by tile to its final position, by one wavefront per waveform.
+//
+// The arithmetic of a tile (packed 16-bit code lengths, DPP scan, lane-local concatenation, ds_or) is drx_encode.h, the
+// same code k_encode_fused runs; reference: src/deltaRice.c:49-63 (delta), :191-244 (Rice code), :383-441 (framing).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "drx_internal.h"
+#include "drx_device.h"
+#include "drx_encode.h"
+
+namespace drx {
+
+namespace {
+
+struct PcChunk {
+    uint64_t c;           // chunk
+    uint64_t sample_off;  // its first sample
+    uint64_t wave_base;   // its first waveform
+    uint32_t n_samples, L, W;
+    uint32_t j;  // workgroup inside the chunk
+};
+
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t rfl64(uint64_t v) { return ((uint64_t)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v); }
+
+// workgroup (ticket) T -> chunk
+__device__ __forceinline__ PcChunk pc_locate(const Geom &G, uint32_t T) {
+    PcChunk q;
+    if (G.uniform) {
+        const uint32_t wgs = piece_shape(G.u_wave_len, G.u_n_waves).wgs;
+        q.c = T / wgs;
+        q.j = T - (uint32_t)q.c * wgs;
+        q.sample_off = q.c * (uint64_t)G.u_n_samples;
+        q.wave_base = q.c * (uint64_t)G.u_n_waves;
+        q.n_samples = G.u_n_samples;
+        q.L = G.u_wave_len;
+        q.W = G.u_n_waves;
+    } else {
+        uint64_t lo = 0, hi = G.n_chunks;  // invariant: pc_wg_base[lo] <= T < pc_wg_base[hi]
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (G.pc_wg_base[mid] <= T) lo = mid; else hi = mid;
+        }
+        const ChunkDesc d = G.chunks[lo];
+        q.c = lo;
+        q.j = T - G.pc_wg_base[lo];
+        q.sample_off = d.sample_off;
+        q.wave_base = d.wave_base;
+        q.n_samples = d.n_samples;
+        q.L = d.wave_len;
+        q.W = d.n_waves;
+    }
+    return q;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const int16_t *__restrict__ in, uint64_t in_samples,
+                                                                 uint32_t *__restrict__ out, uint64_t out_cap,
+                                                                 uint64_t *__restrict__ chunk_word_off,
+                                                                 uint32_t *__restrict__ wave_words,
+                                                                 uint64_t *__restrict__ scan_state, uint32_t *__restrict__ ticket,
+                                                                 uint32_t total_wgs, DevStatus *st) {
+    // per wavefront: 4 pad words (place_words ORs zeros below a lane's first word), the code, 4 slack words
+    __shared__ __attribute__((aligned(16))) uint32_t buf_all[kPcWaves][kEncCapWords + 8];
+    __shared__ uint32_t s_ticket;
+    __shared__ uint32_t s_n[kPcWaves][kPcMaxRun];  // runs: n_i of the run's waveforms
+    __shared__ uint32_t s_size[kPcWaves];          // runs: words of the run, headers included; segments: bits of the segment
+    __shared__ uint32_t s_fit[kPcWaves];           // the piece is in its buffer
+    __shared__ uint64_t s_excl;
+    const int lane = lane_id();
+    const uint32_t wv = rfl(threadIdx.x >> 6);
+    uint32_t *row = buf_all[wv];
+    uint32_t *buf = row + 4;
+    const uint32_t buf_bits = lds_addr(buf) * 8u;
+
+    if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1u);
+    for (int i = lane; i < (int)(kEncCapWords + 8) / 4; i += 64) reinterpret_cast<uint4 *>(row)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const uint32_t T = s_ticket;
+    if (T >= total_wgs) return;  // (the grid is exactly total_wgs workgroups)
+    PcChunk q = pc_locate(G, T);
+    q.n_samples = rfl(q.n_samples); q.L = rfl(q.L); q.W = rfl(q.W); q.j = rfl(q.j);
+    q.sample_off = rfl64(q.sample_off); q.wave_base = rfl64(q.wave_base); q.c = rfl64(q.c);
+    const PieceShape sh = piece_shape(q.L, q.W);
+    const uint32_t p = rfl(q.j * kPcWaves + wv);  // piece of the chunk
+    const bool live = p < sh.pieces;
+    const bool runs = sh.run > 1u;
+    const uint32_t S = sh.segs;
+    const uint32_t k = G.k;
+
+    // what this wavefront encodes: `nspans` spans of samples, contiguous in memory from x on
+    //   runs:     span i = waveform w0 + i of the chunk (whole);        segments: one span = segment sg of waveform w0
+    const uint32_t w0 = runs ? p * sh.run : p / S;
+    const uint32_t sg = runs ? 0u : p % S;
+    uint32_t nspans = 0;
+    uint32_t wf_len = 0;  // segments: samples of the whole waveform
+    if (live) {
+        if (runs) {
+            nspans = q.W - w0 < sh.run ? q.W - w0 : sh.run;
+        } else {
+            wf_len = (w0 + 1u == q.W) ? q.n_samples - w0 * q.L : q.L;
+            nspans = sg * sh.seg_len < wf_len ? 1u : 0u;
+        }
+    }
+    const uint64_t wf_off = q.sample_off + (uint64_t)w0 * q.L;  // first sample of waveform w0 in the batch
+    const uint64_t xoff = wf_off + (uint64_t)sg * sh.seg_len;   // first sample of this piece
+    auto span_len = [&](uint32_t i) -> uint32_t {
+        if (runs) return (w0 + i + 1u == q.W) ? q.n_samples - (w0 + i) * q.L : q.L;
+        const uint32_t left = wf_len - sg * sh.seg_len;
+        return left < sh.seg_len ? left : sh.seg_len;
+    };
+    // the sample in front of a segment (a waveform's first sample has none: x[-1] := 0, src/deltaRice.c:53-54)
+    uint32_t carry0 = 0;
+    if (!runs && sg && nspans) carry0 = (uint32_t)(uint16_t)in[xoff - 1u] << 16;
+
+    // ---- the tiles of all spans as one sequence: loads run kDepth tiles ahead, across span boundaries ----
+    struct Cursor { uint32_t i, off, rem; };  // span, sample offset of the tile from xoff, samples of the span from this tile on
+    auto cur_first = [&]() -> Cursor { Cursor c; c.i = 0; c.off = 0; c.rem = nspans ? span_len(0) : 0u; return c; };
+    auto cur_next = [&](Cursor &c) {
+        if (c.i >= nspans) return;
+        if (c.rem > (uint32_t)kTile) { c.off += (uint32_t)kTile; c.rem -= (uint32_t)kTile; return; }
+        c.off += c.rem;  // (runs: the next waveform follows in memory)
+        c.i += 1u;
+        c.rem = c.i < nspans ? span_len(c.i) : 0u;
+    };
+    // branch-free 16-byte load at any int16 alignment, clamped to the batch: a lane whose 8 samples would pass the end of
+    // the input reads the last 8 samples instead and shifts them into place when the tile is consumed (fix_tail)
+    const uint64_t last8 = in_samples - 8u;  // (pieces_batch(): the batch has at least one tile of samples)
+    auto load_item = [&](const Cursor &c) -> uint4 {
+        const uint64_t gi = xoff + (c.i < nspans ? c.off : 0u) + 8u * (uint32_t)lane;
+        const uint64_t a = gi < last8 ? gi : last8;
+        return *reinterpret_cast<const uint4 *>(in + a);
+    };
+    auto fix_tail = [&](const Cursor &c, uint32_t (&w)[4]) {
+        const uint64_t gi = xoff + c.off + 8u * (uint32_t)lane;
+        if (gi > last8) {  // rare: the last lanes of the batch's last tile
+            const uint32_t d = (uint32_t)(gi - last8);  // samples to drop from the front (1..7 matter; more: nothing valid)
+            for (uint32_t s = 0; s < d && s < 8u; ++s) {
+                w[0] = __builtin_amdgcn_alignbit(w[1], w[0], 16);
+                w[1] = __builtin_amdgcn_alignbit(w[2], w[1], 16);
+                w[2] = __builtin_amdgcn_alignbit(w[3], w[2], 16);
+                w[3] >>= 16;
+            }
+        }
+    };
+
+    uint32_t wpos = 0;   // runs: word of buf where the current waveform's header goes
+    uint32_t Pw = 0;     // bits of the current span so far
+    bool fits = true;    // everything so far is in buf
+    uint32_t carry = 0;  // dword whose high half is the sample before the tile
+    auto process = [&](const Cursor &c, const uint4 &qv, auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULLT = decltype(full_tag)::value;
+        uint32_t w[4] = {qv.x, qv.y, qv.z, qv.w};
+        if (!FULLT) fix_tail(c, w);
+        uint32_t xprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[3], 0x138, 0xf, 0xf, false);  // wave_shr:1
+        if (lane == 0) xprev = carry;
+        carry = (uint32_t)__builtin_amdgcn_readlane((int)w[3], 63);
+        PackedCodes pc;
+        const u16x2 tp[4] = {splat(1u), splat(0xffffu), splat(0u), splat(0u)};
+        packed_codes<false>(w, xprev, 0u, tp, k, pc);
+        if (!FULLT) {
+            const uint32_t l8 = 8u * (uint32_t)lane;
+            const int nv = c.rem <= l8 ? 0 : (int)(c.rem - l8 < 8u ? c.rem - l8 : 8u);
+            mask_tail(pc, nv);
+        }
+        const uint32_t lane_bits = lane_tile_bits(pc);
+        uint32_t cw[4];
+        if (FULLT) concat_codes(pc, cw);
+        const uint32_t incl = wave_incl_scan_dpp(lane_bits);
+        const uint32_t tile_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t P = (runs ? 32u * (wpos + 1u) : 0u) + Pw;  // bit of buf where the tile starts
+        if (fits && ((P + tile_bits + 31u) >> 5) < kEncCapWords) {
+            if (FULLT && !__any(lane_bits > 128u))
+                place_words(cw, buf_bits + P + incl);
+            else
+                emit_tile<FULLT>(pc, buf_bits + P + incl - lane_bits);
+        } else {
+            fits = false;
+        }
+        Pw += tile_bits;
+    };
+    auto consume = [&](Cursor &c, const uint4 &qv) __attribute__((always_inline)) {
+        if (c.i >= nspans) return;
+        if (c.rem >= (uint32_t)kTile) process(c, qv, std::true_type{}); else process(c, qv, std::false_type{});
+        if (c.rem <= (uint32_t)kTile) {  // the span's last tile
+            if (runs) {
+                const uint32_t n = (Pw + 31u) >> 5;
+                if (lane == 0) {
+                    if (fits) buf[wpos] = n;
+                    s_n[wv][c.i] = n;
+                }
+                wpos += 1u + n;
+                Pw = 0;
+                carry = 0;  // the next waveform starts from x[-1] := 0
+            }
+        }
+        cur_next(c);
+    };
+    {
+        constexpr int kDepth = 3;
+        carry = carry0;
+        Cursor pcur = cur_first(), lcur = pcur;
+        uint4 qv[kDepth];
+#pragma unroll
+        for (int u = 0; u < kDepth; ++u) { qv[u] = load_item(lcur); cur_next(lcur); }
+#pragma unroll 1
+        while (pcur.i < nspans) {
+#pragma unroll
+            for (int u = 0; u < kDepth; ++u) {
+                consume(pcur, qv[u]);
+                qv[u] = load_item(lcur);
+                cur_next(lcur);
+            }
+        }
+    }
+    wave_sync();
+    if (lane == 0) {
+        s_size[wv] = runs ? wpos : Pw;
+        s_fit[wv] = fits ? 1u : 0u;
+    }
+    __syncthreads();
+
+    // ---- sizes of this workgroup's waveforms, look-back ----
+    const bool first_wg = q.j == 0u;
+    // segments: the group of S wavefronts of my waveform, its bits before my segment, its words, the words of the
+    // groups in front of it, and whether every segment of the group is in its buffer
+    const uint32_t gb = runs ? wv : (wv & ~(S - 1u));
+    uint32_t bits_before = 0, grp_bits = 0, words_before = 0, block_words = 0;
+    bool grp_fit = true;
+    if (runs) {
+#pragma unroll
+        for (uint32_t i = 0; i < kPcWaves; ++i) {
+            const uint32_t sz = s_size[i];
+            words_before += i < wv ? sz : 0u;
+            block_words += sz;
+        }
+        grp_fit = fits;
+    } else {
+#pragma unroll
+        for (uint32_t g0 = 0; g0 < kPcWaves; g0 += 1u) {
+            if ((g0 & (S - 1u)) != 0u) continue;  // first wavefront of a group
+            uint32_t gbits = 0;
+            bool gf = true;
+            for (uint32_t s = 0; s < S; ++s) {
+                const uint32_t b = s_size[g0 + s];
+                if (g0 == gb && s < sg) bits_before += b;
+                gbits += b;
+                gf = gf && s_fit[g0 + s];
+            }
+            const bool glive = (q.j * kPcWaves + g0) < sh.pieces;
+            const uint32_t gw = glive ? 1u + ((gbits + 31u) >> 5) : 0u;
+            if (g0 < gb) words_before += gw;
+            if (g0 == gb) { grp_bits = gbits; grp_fit = gf; }
+            block_words += gw;
+        }
+    }
+    const uint64_t block_sum = (uint64_t)block_words + (first_wg ? 1ull : 0ull);
+    if (wv == 0) {
+        uint64_t excl_blk = 0;
+        if (T == 0) {
+            if (lane == 0) __hip_atomic_store(scan_state + T, kScanPrefix | block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            // decoupled look-back over one entry per workgroup, 128 entries per poll (as in k_encode_fused)
+            if (lane == 0) __hip_atomic_store(scan_state + T, kScanAgg | block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int64_t base = (int64_t)T - 1;
+            uint32_t spins = 0;
+            for (;;) {
+                const int64_t i0 = base - lane, i1 = base - 64 - lane;
+                uint64_t s0v = kScanPrefix, s1v = kScanPrefix;
+                if (i0 >= 0) s0v = __hip_atomic_load(scan_state + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (i1 >= 0) s1v = __hip_atomic_load(scan_state + i1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t st0 = (uint32_t)(s0v >> 62), st1 = (uint32_t)(s1v >> 62);
+                const uint64_t p0 = __ballot(st0 == 2u), z0 = __ballot(st0 == 0u);
+                const uint64_t p1 = __ballot(st1 == 2u), z1 = __ballot(st1 == 0u);
+                const int fp = p0 ? __builtin_ctzll(p0) : (p1 ? 64 + __builtin_ctzll(p1) : 128);
+                const uint64_t near0 = fp >= 64 ? ~0ull : ((1ull << fp) - 1ull);
+                const uint64_t near1 = fp >= 128 ? ~0ull : (fp > 64 ? ((1ull << (fp - 64)) - 1ull) : 0ull);
+                if ((z0 & near0) | (z1 & near1)) {  // a nearer predecessor has not published yet
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 22)) {  // cannot happen with a zeroed scan_state; never hang the GPU
+                        if (lane == 0) atomicOr(&st->err, kErrInternal);
+                        break;
+                    }
+                    continue;
+                }
+                const uint64_t c0 = (lane <= fp) ? (s0v & kScanValMask) : 0ull;
+                const uint64_t c1 = (64 + lane <= fp) ? (s1v & kScanValMask) : 0ull;
+                excl_blk += wave_sum_u64(c0 + c1);
+                if (fp < 128) break;
+                base -= 128;
+            }
+            if (lane == 0)
+                __hip_atomic_store(scan_state + T, kScanPrefix | (excl_blk + block_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            s_excl = excl_blk;
+            if (first_wg) {
+                chunk_word_off[q.c] = excl_blk;
+                if (excl_blk < out_cap) out[excl_blk] = q.n_samples;  // chunk header, src/deltaRice.c:415
+            }
+            if (T + 1u == total_wgs) {
+                chunk_word_off[G.n_chunks] = excl_blk + block_sum;
+                st->total_words = excl_blk + block_sum;
+                if (excl_blk + block_sum > out_cap) atomicOr(&st->err, kErrCapacity);
+            }
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    const uint64_t pos = s_excl + (first_wg ? 1ull : 0ull) + words_before;  // runs: first header of the run; segments: the waveform's header
+
+    // a waveform coded once more, tile by tile, straight to its place (its code did not fit the buffer)
+    auto stream_waveform = [&](uint64_t soff, uint32_t len, uint32_t *__restrict__ outp) {
+        for (int i = lane; i < (int)(kEncCapWords + 8) / 4; i += 64) reinterpret_cast<uint4 *>(row)[i] = make_uint4(0, 0, 0, 0);
+        wave_sync();
+        const int16_t *x = in + soff;
+        uint64_t P = 0;
+        uint32_t cr = 0;
+        const u16x2 tp[4] = {splat(1u), splat(0xffffu), splat(0u), splat(0u)};
+        for (uint32_t t0 = 0; t0 < len; t0 += kTile) {
+            uint32_t w[4];
+            const int nv = load8_dwords(x, len, t0, lane, true, w);
+            uint32_t xprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[3], 0x138, 0xf, 0xf, false);
+            if (lane == 0) xprev = cr;
+            cr = (uint32_t)__shfl((int)w[3], 63);
+            PackedCodes pc;
+            packed_codes<false>(w, xprev, 0u, tp, k, pc);
+            mask_tail(pc, nv);
+            const uint32_t lane_bits = lane_tile_bits(pc);
+            const uint32_t incl = wave_incl_scan_dpp(lane_bits);
+            const uint32_t tile_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            const uint64_t wfirst = P >> 5;  // first staged word
+            emit_tile<false>(pc, buf_bits + (uint32_t)(P & 31u) + incl - lane_bits);
+            P += tile_bits;
+            wave_sync();
+            const uint32_t nfull = (uint32_t)((P >> 5) - wfirst);
+            for (uint32_t i = lane; i < nfull; i += 64) { outp[wfirst + i] = buf[i]; buf[i] = 0; }
+            wave_sync();
+            if (nfull && lane == 0) { const uint32_t cwd = buf[nfull]; buf[nfull] = 0; buf[0] = cwd; }
+            wave_sync();
+        }
+        if ((P & 31u) && lane == 0) outp[P >> 5] = buf[0];
+    };
+
+    if (runs) {
+        const uint32_t words = s_size[wv];
+        if ((uint32_t)lane < nspans) wave_words[q.wave_base + w0 + (uint32_t)lane] = s_n[wv][lane];
+        if (pos + words > out_cap) return;  // the last workgroup raises kErrCapacity
+        if (fits) {
+            for (uint32_t i = lane; i < words; i += 64) out[pos + i] = buf[i];
+            return;
+        }
+        uint64_t at = pos;
+        for (uint32_t i = 0; i < nspans; ++i) {
+            const uint32_t n = s_n[wv][i];
+            if (lane == 0) out[at] = n;  // src/deltaRice.c:379
+            wave_sync();
+            stream_waveform(wf_off + (uint64_t)i * q.L, span_len(i), out + at + 1u);
+            at += 1u + n;
+        }
+        return;
+    }
+
+    const uint32_t n = (grp_bits + 31u) >> 5;  // the waveform's payload words
+    if (sg == 0u && lane == 0) wave_words[q.wave_base + w0] = n;
+    if (pos + 1u + n > out_cap) return;
+    if (sg == 0u && lane == 0) out[pos] = n;
+    uint32_t *__restrict__ outp = out + pos + 1u;
+    if (!grp_fit) {
+        if (sg == 0u) stream_waveform(wf_off, wf_len, outp);
+        return;
+    }
+    // my words of the waveform's stream: those whose FIRST bit lies in my segment
+    const uint32_t my_bits = s_size[wv];
+    const uint32_t B = bits_before, E = bits_before + my_bits;
+    const uint32_t w_lo = (B + 31u) >> 5, w_hi = (E + 31u) >> 5;
+    const uint32_t *nbuf = buf_all[(wv + 1u) & (kPcWaves - 1u)] + 4;  // segment sg + 1 (read only where it exists)
+    const bool has_next = sg + 1u < S;
+    for (uint32_t w = w_lo + (uint32_t)lane; w < w_hi; w += 64u) {
+        const uint32_t o = 32u * w - B, a = o >> 5, r = o & 31u;
+        uint32_t v = r ? __builtin_amdgcn_alignbit(buf[a], buf[a + 1u], 32u - r) : buf[a];
+        const uint32_t nb = E - 32u * w;  // my bits in this word from its top (>= 1)
+        if (nb < 32u && has_next) v |= nbuf[0] >> nb;
+        outp[w] = v;
+    }
+}
+
+// The batches this encoder takes: delta filter, every WaveformLength within [kPcMinLen, kPcMaxLen], and a shape
+// k_encode_fused is bad at somewhere (a chunk of short or of long waveforms).  Measured against the segment encoder at 100 /
+// 5 / 1 chunks of 14 M samples (GB/s of int16): L = 512 2085 / 1374 / 669 against 973 / 592 / 220, L = 2048 2139 / 1494 / 664
+// against 1633 / 1125 / 482, L = 16 384 2299 / 1364 / 702 against 1791 / 1265 / 504, L = 65 536 2319 / 1400 / 669 against
+// 1629 / 1237 / 511 (profiles/r02_notes.md): no lower bound on the batch size.  Waveforms longer than kPcMaxLen (the
+// reference's default, one waveform per chunk) stay with the segment encoder, which cuts them into as many pieces as it likes.
+// debug_flags: 4096 never this encoder, 8192 always the segment encoder, 32768 this encoder also where WaveformLength is in
+// k_encode_fused's own range (one waveform per wavefront; the tests compare the two that way).
+bool pieces_batch(const Geom &G) {
+    if (G.n_taps || (G.dbg & (8192u | 4096u))) return false;
+    const bool force = (G.dbg & 32768u) != 0;
+    if (G.uniform) {
+        const uint32_t L = G.u_wave_len;
+        if (L < kPcMinLen || L > kPcMaxLen) return false;
+        if ((uint64_t)G.n_chunks * G.u_n_samples < (uint64_t)kTile) return false;
+        const PieceShape sh = piece_shape(L, G.u_n_waves);
+        if ((uint64_t)sh.wgs * G.n_chunks > 0x7fffffffull) return false;
+        return force || sh.run > 1u || sh.segs > 1u;
+    }
+    return G.pc_wg_base != nullptr;  // decided when the plan was made
+}
+
+uint64_t pieces_workgroups(const Geom &G, const ChunkDesc *host_chunks) {
+    if (G.uniform) return (uint64_t)piece_shape(G.u_wave_len, G.u_n_waves).wgs * G.n_chunks;
+    uint64_t t = 0;
+    for (uint64_t c = 0; c < G.n_chunks; ++c) t += piece_shape(host_chunks[c].wave_len, host_chunks[c].n_waves).wgs;
+    return t;
+}
+
+hipError_t launch_encode_pieces(const Geom &G, const int16_t *d_in, uint64_t in_samples, uint32_t *d_out, uint64_t out_cap,
+                                uint64_t *d_chunk_word_off, uint32_t *d_wave_words, uint64_t *d_scan, uint64_t total_wgs,
+                                DevStatus *d_status, hipEvent_t *ev, hipStream_t s) {
+    if (G.total_waves == 0 || total_wgs == 0) return hipSuccess;
+    if (ev) (void)hipEventRecord(ev[0], s);
+    // look-back entries (one per workgroup) + the ticket word behind them, zeroed on the stream before every launch
+    hipError_t e = hipMemsetAsync(d_scan, 0, (total_wgs + 2) * sizeof(uint64_t), s);
+    if (e != hipSuccess) return e;
+    if (ev) { (void)hipEventRecord(ev[1], s); (void)hipEventRecord(ev[2], s); }
+    uint32_t *ticket = reinterpret_cast<uint32_t *>(d_scan + total_wgs);
+    k_encode_pieces<<<(unsigned)total_wgs, 64 * kPcWaves, 0, s>>>(G, d_in, in_samples, d_out, out_cap, d_chunk_word_off, d_wave_words,
+                                                                d_scan, ticket, (uint32_t)total_wgs, d_status);
+    if (ev) (void)hipEventRecord(ev[3], s);
+    return hipGetLastError();
+}
+
+}  // namespace drx

@@ -33,8 +33,8 @@ def dev(ctx, a):
 
 def gpu_encode(ctx, plan, x):
     """Encodes with every encoder (the simple size/scan/pack passes; the single pass with look-back, forced
-    with debug flag 256; and whatever the batch shape selects by default, which is the segment encoder for
-    short and for few long waveforms), checks they agree, returns the default one's result."""
+    with debug flag 256; the pieces encoder wherever its geometry allows, flag 32768; and whatever the batch shape
+    selects by default), checks they agree, returns the default one's result."""
     xd = dev(ctx, x.reshape(-1).view(np.int16))
     ctx.set_option("encode_impl", 0)
     enc0 = plan.encode(xd)
@@ -42,11 +42,17 @@ def gpu_encode(ctx, plan, x):
     ctx.set_option("encode_impl", 1)
     ctx.set_option("debug_flags", 256)
     w1, off1 = plan.encode(xd).to_numpy()
+    ctx.set_option("debug_flags", 32768)
+    w2, off2 = plan.encode(xd).to_numpy()
+    ctx.set_option("debug_flags", 4096)
+    w3, off3 = plan.encode(xd).to_numpy()
     ctx.set_option("debug_flags", 0)
     enc = plan.encode(xd)
     w, off = enc.to_numpy()
     assert np.array_equal(off, off0) and np.array_equal(w, w0), "encoder implementations disagree"
     assert np.array_equal(off1, off0) and np.array_equal(w1, w0), "single-pass encoder disagrees"
+    assert np.array_equal(off2, off0) and np.array_equal(w2, w0), "pieces encoder disagrees"
+    assert np.array_equal(off3, off0) and np.array_equal(w3, w0), "encoder without the pieces path disagrees"
     return enc, w, off
 
 
@@ -173,6 +179,84 @@ def test_ragged_mixed_waveform_lengths(ctx, O):
         ctx.set_option("decode_impl", impl)
         assert np.array_equal(plan.decode(enc).cpu().numpy(), x)
     ctx.set_option("decode_impl", 8)
+
+
+PIECE_CASES = [
+    # (n_chunks, chunk_samples, L, k, kind): runs of short waveforms, segments of long ones (drx_pieces.hip)
+    (3, 64 * 50 + 7, 64, 3, "gauss10"),        # 16 waveforms per run, partial tiles only, leftover waveform
+    (2, 100 * 333, 100, 3, "steps"),
+    (4, 512 * 40, 512, 3, "gauss10"),          # whole tiles, 12 per run
+    (2, 700 * 29 + 13, 700, 2, "gauss300"),    # a full and a partial tile per waveform
+    (3, 1024 * 17, 1024, 3, "gauss10"),
+    (2, 2048 * 9 + 17, 2048, 3, "gauss10"),    # three per run
+    (2, 3072 * 5, 3072, 3, "gauss10"),         # two per run
+    (3, 3073 * 4, 3073, 3, "gauss10"),         # one waveform per wavefront
+    (2, 9000 * 3 + 100, 9000, 3, "gauss10"),   # two segments (4608 samples each)
+    (2, 16384 * 5, 16384, 3, "gauss10"),
+    (2, 20000 * 3 + 4000, 20000, 3, "gauss10"),  # four segments; the leftover waveform fills one of them
+    (1, 40000 * 3, 40000, 4, "gauss300"),      # eight segments
+    (2, 65536 + 30000, 65536, 3, "gauss10"),
+    (2, 512 * 30, 512, 3, "uniform"),          # incompressible: runs outgrow the LDS buffer, coded again to their place
+    (2, 2048 * 5, 2048, 3, "uniform"),
+    (2, 16384 * 3, 16384, 3, "uniform"),       # ... and so do segments
+    (1, 40000 * 2, 40000, 3, "steps"),
+    (2, 16384 * 2, 16384, 3, "zeros"),         # 4 bits per sample: segment boundaries inside words
+    (2, 512 * 20, 512, 0, "zeros"),            # one bit per sample
+    (2, 20000 * 2, 20000, 0, "zeros"),
+    (3, 2000 * 10, 2000, 15, "uniform"),
+]
+
+
+@pytest.mark.parametrize("n_chunks,chunk_samples,L,k,kind", PIECE_CASES)
+def test_pieces_encoder_vs_oracle(ctx, O, n_chunks, chunk_samples, L, k, kind):
+    rng = np.random.default_rng(hash((n_chunks, chunk_samples, L, k)) & 0xFFFF)
+    x = make_data(rng, kind, n_chunks * chunk_samples)
+    opts = (1 << k, L)
+    ref_w, ref_off = O.encode_batch(x, chunk_samples, opts)
+    plan = ctx.plan_uniform(n_chunks, chunk_samples, opts)
+    ctx.set_option("debug_flags", 32768)
+    try:
+        enc = plan.encode(dev(ctx, x))
+        w, off = enc.to_numpy()
+        nw = plan.wave_words()
+    finally:
+        ctx.set_option("debug_flags", 0)
+    assert np.array_equal(off, ref_off)
+    bad = np.flatnonzero(w != ref_w) if w.size == ref_w.size else None
+    assert np.array_equal(w, ref_w), f"first differing word {None if bad is None else bad[:4]}"
+    assert int(nw.sum()) + nw.size + n_chunks == ref_w.size
+    assert np.array_equal(plan.decode(enc).cpu().numpy(), x)
+
+
+def test_pieces_encoder_ragged_and_capacity(ctx, O):
+    rng = np.random.default_rng(77)
+    Ls = [512, 16384, 2048, 7000, 100, 40000, 512, 9000]
+    Ns = [512 * 33 + 5, 16384 * 3 + 9000, 2048 * 7, 7000 * 3, 100 * 41, 40000 * 2 + 1, 512, 9000 * 2]
+    xs = [make_data(rng, "uniform" if c == 2 else "gauss10", n) for c, n in enumerate(Ns)]
+    x = np.concatenate(xs)
+    plan = ctx.plan(Ns, Ls, 8)
+    ctx.set_option("debug_flags", 32768)
+    try:
+        enc = plan.encode(dev(ctx, x))
+        w, off = enc.to_numpy()
+        at = 0
+        for c, (xc, L) in enumerate(zip(xs, Ls)):
+            ref = O.encode_chunk(xc, (8, L))
+            assert off[c] == at
+            assert np.array_equal(w[at:at + ref.size], ref), f"chunk {c}"
+            at += ref.size
+        assert off[-1] == at == enc.total_words
+        assert np.array_equal(plan.decode(enc).cpu().numpy(), x)
+        # an output buffer one word short: DRX_ERR_CAPACITY
+        import deltarice_amd as dr
+        for cap in (at - 1, at // 2, 10):
+            with pytest.raises(dr.DeltaRiceError) as e:
+                plan.encode(dev(ctx, x), capacity_words=cap)
+            assert e.value.status == 3
+        w2, off2 = plan.encode(dev(ctx, x), capacity_words=at).to_numpy()  # exactly enough; the plan is still usable
+        assert np.array_equal(w2, w) and np.array_equal(off2, off)
+    finally:
+        ctx.set_option("debug_flags", 0)
 
 
 def test_decode_chunks_in_arbitrary_order(ctx, O):

@@ -364,14 +364,14 @@ drx_status drx_plan_create(drx_ctx *ctx, uint64_t n_chunks, const uint32_t *chun
         // parallel header walks for small ragged batches: every long-waveform chunk within the chunk-wide walk's
         // capacity, every short-waveform chunk worth the two block passes (same limits as for uniform batches)
         {
-            bool ok = p->n_long <= kPwMaxChunks && p->n_short <= 150u;
+            bool ok = p->n_long <= kPwMaxChunks && p->n_short <= kPwMaxChunks;
             uint64_t bmax = 0;
             for (uint64_t c = 0; c < n_chunks && ok; ++c) {
                 const ChunkDesc &d = desc[c];
                 if (d.wave_len > kWalkShortLenHost) {
                     ok = d.n_waves <= kPwMaxWaves;
                 } else {
-                    ok = d.wave_len >= 16u && p->n_short <= d.n_waves / 100u;
+                    ok = d.wave_len >= 16u && p->n_short <= d.n_waves / 60u;
                     const uint64_t mw = 1u + 2ull * d.n_waves + (((uint64_t)d.n_samples * 25u + 31u) >> 5);
                     bmax = std::max<uint64_t>(bmax, (mw + 4095u) / 4096u);
                 }

@@ -1243,145 +1243,187 @@ __global__ __launch_bounds__(64) void k_walk_block(Geom G, const uint32_t *__res
 
 // The same idea for chunks of SHORT waveforms (tens of thousands of headers per chunk: too many for one
 // workgroup's LDS, and the chain chase through LDS still costs 0.13 us per hop, 3.6 ms for 14 M samples at
-// L = 512).  A header is at most max_words = 25 L / 32 (400 for L = 512) and every 4096-word block of the stream
-// holds several of them, so the BLOCKS become independent: a wavefront loads its block, takes the first word <=
-// max_words as the block's entry header, chases the chain through LDS to the block's end (if the chain breaks,
+// L = 512).  A header is at most max_words = 25 L / 32 (400 for L = 512) and every B-word block of the stream with
+// B > max_words holds at least one, so the BLOCKS become independent: a wavefront loads its block, takes the first word in
+// [1, max_words] as the block's entry header, chases the chain through LDS to the block's end (if the chain breaks,
 // the entry was an impostor: try the next small word), and reports {entry, headers, exit}.  k_bw_scan checks per
 // chunk that every block's exit is the next block's entry (and word 1 / the chunk end at the two ends) and
 // turns the counts into first-waveform indices; k_bw_blocks then runs again and writes the table.  A chunk
 // that does not stitch is flagged and walked by k_walk_block.
+// Launch shape.  How many blocks a chunk really has is only known on the device (chunk_word_off), while the host can only
+// bound it by 25 bits per sample, four times the usual: a grid with a workgroup per POSSIBLE block spent most of its time
+// on empty workgroups, each holding its LDS for a few microseconds.  So the grid is a fixed number of wavefronts (as many as
+// the LDS lets the chip hold) that stride over the REAL blocks, numbered through a prefix sum over the chunks' block
+// counts that every wavefront computes for itself (at most kBwMaxList chunks).  B is the smallest of 1024 / 2048 / 4096
+// that exceeds max_words: the chase is a chain of dependent LDS reads, so what hides it is wavefronts per CU, i.e.
+// little LDS per block.  (A one-pass version -- blocks in ticket order, {headers, exit} through a decoupled look-back,
+// table written straight from LDS -- was built and measured SLOWER than the two passes, 0.97 against 0.88 ms on config 5:
+// the frontier of known prefixes advances one window of entries per memory round trip; profiles/r02_notes.md.)
 constexpr uint32_t kBwTries = 6;  // impostors tolerated in front of a block's first real header
+constexpr uint32_t kBwMaxList = 256;  // chunks per launch (bw_walk_blocks_max() / the plan admit at most 224)
 
 struct BwBlock { uint32_t entry, count, exit, base; };
 
-template <bool EMIT>
+// pre[s] = real blocks of the listed chunks in front of chunk s (pre[n_list] = all); a chunk whose extent is unusable has
+// none (k_bw_scan flags it), one longer than the host's bound is cut there (ditto)
+template <uint32_t B>
+__device__ __forceinline__ void bw_block_prefix(const uint64_t *__restrict__ chunk_word_off, uint64_t in_words,
+                                                const uint32_t *__restrict__ list, uint32_t n_list, uint32_t blocks_max,
+                                                uint32_t *pre, int lane) {
+    uint32_t run = 0;
+    for (uint32_t s0 = 0; s0 < n_list; s0 += 64u) {
+        const uint32_t sl = s0 + (uint32_t)lane;
+        uint32_t nb = 0;
+        if (sl < n_list) {
+            const uint64_t c = list ? (uint64_t)list[sl] : sl;
+            const uint64_t begin = chunk_word_off[c], end = chunk_word_off[c + 1];
+            const bool bad = end > in_words || begin + 2 > end || end - begin > 0x7fffffffull;
+            if (!bad) nb = (uint32_t)((end - begin + B - 1u) / B);
+            if (nb > blocks_max) nb = blocks_max;
+        }
+        const uint32_t incl = wave_incl_scan_dpp(nb);
+        if (sl < n_list) pre[sl + 1u] = run + incl;
+        run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    if (lane == 0) pre[0] = 0;
+    wave_sync();
+}
+
+template <uint32_t B, bool EMIT>
 __global__ __launch_bounds__(64) void k_bw_blocks(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
                                                   const uint64_t *__restrict__ chunk_word_off, const uint32_t *__restrict__ list,
                                                   uint32_t n_list, uint32_t blocks_max,
                                                   BwBlock *__restrict__ info, const uint32_t *__restrict__ fail,
                                                   uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
                                                   DevStatus *st) {
-    constexpr uint32_t B = kWalkBlockWords;
     constexpr int NV = B / 256;
     __shared__ __attribute__((aligned(16))) uint32_t blk[B];
-    __shared__ __attribute__((aligned(8))) uint2 hop[kWalkHopCap];
+    __shared__ uint16_t hop[EMIT ? B / 2 : 2];  // header positions inside the block (a waveform has at least one payload word)
+    __shared__ uint32_t pre[kBwMaxList + 1];
     const int lane = lane_id();
-    const uint64_t unit = blockIdx.x;          // info[] is indexed by list slot, fail[] by chunk
-    const uint64_t slot = unit / blocks_max;
-    const uint32_t b = (uint32_t)(unit - slot * blocks_max);
-    if (slot >= n_list) return;
-    const uint64_t c = list ? (uint64_t)list[slot] : slot;
-    if (EMIT && fail[c]) return;
-    uint32_t W, L, n_samples;
-    uint64_t wbase;
-    if (G.uniform) { W = G.u_n_waves; L = G.u_wave_len; n_samples = G.u_n_samples; wbase = c * W; }
-    else { const ChunkDesc d = G.chunks[c]; W = d.n_waves; L = d.wave_len; n_samples = d.n_samples; wbase = d.wave_base; }
-    const uint64_t begin = chunk_word_off[c], end = chunk_word_off[c + 1];
-    if (end > in_words || begin + 2 > end || end - begin > 0x7fffffffull) return;  // k_bw_scan flags the chunk
-    const uint32_t len_w = (uint32_t)(end - begin);
-    const uint32_t b0 = b * B;  // block = words [b0, b0 + B) of the chunk
-    if (b0 >= len_w) return;
-    const uint32_t blk_len = len_w - b0 < B ? len_w - b0 : B;
-    const uint32_t max_full = (uint32_t)(((uint64_t)L * 25u + 31u) >> 5);
-    // the block's words into LDS (the same fixed grid of 16-byte quads as walk_chunk_block, relative to the chunk)
-    {
-        const uint64_t a0 = begin + b0;
-        const bool vec_ok = (((uintptr_t)(in + a0)) & 15u) == 0;
+    bw_block_prefix<B>(chunk_word_off, in_words, list, n_list, blocks_max, pre, lane);
+    const uint32_t total = pre[n_list];
+    for (uint32_t unit = blockIdx.x; unit < total; unit += gridDim.x) {
+        wave_sync();  // (the previous block's LDS reads are done)
+        uint32_t lo = 0, hi = n_list;  // invariant: pre[lo] <= unit < pre[hi]
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (pre[mid] <= unit) lo = mid; else hi = mid;
+        }
+        const uint32_t slot = lo, b = unit - pre[lo];
+        const uint64_t c = list ? (uint64_t)list[slot] : slot;
+        if (EMIT && fail[c]) continue;
+        uint32_t W, L, n_samples;
+        uint64_t wbase;
+        if (G.uniform) { W = G.u_n_waves; L = G.u_wave_len; n_samples = G.u_n_samples; wbase = c * W; }
+        else { const ChunkDesc d = G.chunks[c]; W = d.n_waves; L = d.wave_len; n_samples = d.n_samples; wbase = d.wave_base; }
+        const uint64_t begin = chunk_word_off[c], end = chunk_word_off[c + 1];
+        const uint32_t len_w = (uint32_t)(end - begin);  // (a chunk with an unusable extent has no blocks)
+        const uint32_t b0 = b * B;  // block = words [b0, b0 + B) of the chunk
+        if (b0 >= len_w) continue;   // (only a chunk cut at the host's bound; flagged by k_bw_scan)
+        const uint32_t blk_len = len_w - b0 < B ? len_w - b0 : B;
+        const uint32_t max_full = (uint32_t)(((uint64_t)L * 25u + 31u) >> 5);
+        // the block's words into LDS (a fixed grid of 16-byte quads relative to the block)
+        {
+            const uint64_t a0 = begin + b0;
+            const bool vec_ok = (((uintptr_t)(in + a0)) & 15u) == 0;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const uint32_t i = (uint32_t)(j * 64 + lane) * 4u;
-            uint4 v;
-            if (vec_ok && i + 4u <= blk_len) {
-                v = *reinterpret_cast<const uint4 *>(in + a0 + i);
-            } else {
-                v.x = (i + 0u < blk_len) ? in[a0 + i + 0u] : 0xffffffffu;
-                v.y = (i + 1u < blk_len) ? in[a0 + i + 1u] : 0xffffffffu;
-                v.z = (i + 2u < blk_len) ? in[a0 + i + 2u] : 0xffffffffu;
-                v.w = (i + 3u < blk_len) ? in[a0 + i + 3u] : 0xffffffffu;
+            for (int j = 0; j < NV; ++j) {
+                const uint32_t i = (uint32_t)(j * 64 + lane) * 4u;
+                uint4 v;
+                if (vec_ok && i + 4u <= blk_len) {
+                    v = *reinterpret_cast<const uint4 *>(in + a0 + i);
+                } else {
+                    v.x = (i + 0u < blk_len) ? in[a0 + i + 0u] : 0xffffffffu;
+                    v.y = (i + 1u < blk_len) ? in[a0 + i + 1u] : 0xffffffffu;
+                    v.z = (i + 2u < blk_len) ? in[a0 + i + 2u] : 0xffffffffu;
+                    v.w = (i + 3u < blk_len) ? in[a0 + i + 3u] : 0xffffffffu;
+                }
+                *reinterpret_cast<uint4 *>(blk + i) = v;
             }
-            *reinterpret_cast<uint4 *>(blk + i) = v;
         }
-    }
-    wave_sync();
-    uint32_t entry, count = 0, exit_pos = 0;
-    bool found = false;
-    if (EMIT) {
-        entry = info[unit].entry;
-        if (entry == 0xffffffffu) return;  // a last block without a header (k_bw_scan)
-        found = true;
-    } else {
-        // candidates in position order: the first word <= max_words at or after `from` (word 0 of the chunk is its
-        // sample count: block 0 starts at word 1)
-        uint32_t from = b == 0 ? 1u : 0u;
-        entry = 0xffffffffu;
-        for (uint32_t t = 0; t < kBwTries && !found; ++t) {
-            uint32_t first = 0xffffffffu;
-            for (uint32_t i = (uint32_t)lane; i < blk_len; i += 64u) {  // lane-strided: the first hit of a lane is its smallest
-                // (never 0: a waveform has at least one payload word, while the zero-padded LAST word of a waveform is
-                // all zeros whenever its final code ends in zero bits -- an impostor that would chain straight into
-                // the real header behind it)
-                if (i >= from && blk[i] - 1u < max_full) { first = i; break; }
+        wave_sync();
+        if (!EMIT) {
+            // candidates in position order: the first word in [1, max_words] at or after `from` (word 0 of the chunk is its
+            // sample count: block 0 starts at word 1), 256 words per step.  Never 0: a waveform has at least one payload
+            // word, while the zero-padded LAST word of a waveform is all zeros whenever its final code ends in zero bits --
+            // an impostor that would chain straight into the real header behind it
+            uint32_t from = b == 0 ? 1u : 0u;
+            uint32_t entry = 0xffffffffu, count = 0, exit_pos = 0;
+            bool found = false;
+            for (uint32_t t = 0; t < kBwTries && !found; ++t) {
+                uint32_t first = 0xffffffffu;
+                for (uint32_t base = from & ~255u; base < blk_len; base += 256u) {
+                    const uint32_t i = base + 4u * (uint32_t)lane;
+                    const uint4 v = *reinterpret_cast<const uint4 *>(blk + i);  // (all B words were written above)
+                    uint32_t f = 0xffffffffu;
+                    if (i + 3u >= from && i + 3u < blk_len && v.w - 1u < max_full) f = i + 3u;
+                    if (i + 2u >= from && i + 2u < blk_len && v.z - 1u < max_full) f = i + 2u;
+                    if (i + 1u >= from && i + 1u < blk_len && v.y - 1u < max_full) f = i + 1u;
+                    if (i + 0u >= from && i + 0u < blk_len && v.x - 1u < max_full) f = i + 0u;
+                    first = ~wave_max_u32(~f);  // minimum over the wave
+                    if (first != 0xffffffffu) break;
+                }
+                if (first == 0xffffffffu) break;
+                // chase from `first` to the block's end
+                uint32_t rel = first, cnt = 0;
+                bool ok = true;
+                while (rel < blk_len) {
+                    const uint32_t n = __builtin_amdgcn_readfirstlane(blk[rel]);
+                    // (n == 0 is no waveform: at least one bit per sample; it also bounds the headers of a block by B / 2)
+                    if (n - 1u >= max_full || (uint64_t)b0 + rel + 1u + n > len_w) { ok = false; break; }
+                    rel += n + 1u;
+                    ++cnt;
+                }
+                if (ok) { found = true; entry = first; count = cnt; exit_pos = b0 + rel; }
+                else from = first + 1u;
             }
-            first = ~wave_max_u32(~first);  // minimum over the wave
-            if (first == 0xffffffffu) break;
-            // chase from `first` to the block's end
-            uint32_t rel = first, cnt = 0;
-            bool ok = true;
-            while (rel < blk_len) {
-                const uint32_t n = __builtin_amdgcn_readfirstlane(blk[rel]);
-                if (n > max_full || (uint64_t)b0 + rel + 1u + n > len_w) { ok = false; break; }
-                rel += n + 1u;
-                ++cnt;
+            if (lane == 0) {
+                BwBlock o;
+                o.entry = found ? b0 + entry : 0xffffffffu;
+                o.count = count;
+                o.exit = exit_pos;
+                o.base = 0;
+                info[unit] = o;
             }
-            if (ok) { found = true; entry = first; count = cnt; exit_pos = b0 + rel; }
-            else from = first + 1u;
+            continue;
         }
-        if (lane == 0) {
-            BwBlock o;
-            o.entry = found ? b0 + entry : 0xffffffffu;
-            o.count = count;
-            o.exit = exit_pos;
-            o.base = 0;
-            info[unit] = o;
-        }
-        return;
-    }
-    // EMIT: chase again from the accepted entry, writing the table
-    const uint64_t base = wbase + info[unit].base;
-    uint32_t rel = entry - b0, w = 0;
-    while (rel < blk_len) {
-        uint32_t hops = 0;
-        const uint32_t w0 = w;
-        while (rel < blk_len && hops < kWalkHopCap) {
+        // EMIT: chase again from the accepted entry, then write the block's part of the table
+        const BwBlock me = info[unit];
+        if (me.entry == 0xffffffffu) continue;  // a last block without a header (k_bw_scan)
+        uint32_t rel = me.entry - b0, hops = 0;
+        while (rel < blk_len) {
             const uint32_t n = __builtin_amdgcn_readfirstlane(blk[rel]);
-            hop[hops] = make_uint2(rel, n);
+            if (lane == 0) hop[hops] = (uint16_t)rel;
             rel += n + 1u;
-            ++w;
             ++hops;
         }
         wave_sync();
-        for (uint32_t i = lane; i < hops; i += 64) {
-            const uint2 h = hop[i];
-            wave_off[base + w0 + i] = begin + b0 + h.x;
-            wave_words[base + w0 + i] = h.y;
+        for (uint32_t i = (uint32_t)lane; i < hops; i += 64u) {
+            const uint32_t pos = hop[i], n = blk[pos], wi = me.base + i;  // (k_bw_scan accepted the chunk: wi < W)
+            wave_off[wbase + wi] = begin + b0 + pos;
+            wave_words[wbase + wi] = n;
             // the chunk's last waveform may be shorter than the rest: its header has tighter bounds; and no
             // header may be below the minimum of 1 + k bits per sample (the chase only checked the upper bound)
-            if (info[unit].base + w0 + i + 1u == W) {
+            if (wi + 1u == W) {
                 const uint32_t last_len = n_samples - (W - 1u) * L;
-                if (h.y > max_payload_words(last_len) || h.y < min_payload_words(last_len, G.k)) atomicOr(&st->err, kErrCorrupt);
-            } else if (h.y < min_payload_words(L, G.k)) {
+                if (n > max_payload_words(last_len) || n < min_payload_words(last_len, G.k)) atomicOr(&st->err, kErrCorrupt);
+            } else if (n < min_payload_words(L, G.k)) {
                 atomicOr(&st->err, kErrCorrupt);
             }
         }
-        wave_sync();
     }
 }
 
 // one wavefront per chunk: stitch the blocks, first-waveform index of every block, verdict
+template <uint32_t B>
 __global__ __launch_bounds__(64) void k_bw_scan(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
                                                 const uint64_t *__restrict__ chunk_word_off, const uint32_t *__restrict__ list,
-                                                uint32_t blocks_max, BwBlock *__restrict__ info, uint32_t *__restrict__ fail) {
+                                                uint32_t n_list, uint32_t blocks_max, BwBlock *__restrict__ info,
+                                                uint32_t *__restrict__ fail) {
+    __shared__ uint32_t pre[kBwMaxList + 1];
     const int lane = lane_id();
+    bw_block_prefix<B>(chunk_word_off, in_words, list, n_list, blocks_max, pre, lane);
     const uint64_t slot = blockIdx.x;
     const uint64_t c = list ? (uint64_t)list[slot] : slot;
     uint32_t W, L, N;
@@ -1391,9 +1433,9 @@ __global__ __launch_bounds__(64) void k_bw_scan(Geom G, const uint32_t *__restri
     bool bad = end > in_words || begin + 2 > end || end - begin > 0x7fffffffull;
     if (!bad && in[begin] != N) bad = true;
     const uint32_t len_w = bad ? 0u : (uint32_t)(end - begin);
-    const uint32_t n_blocks = (len_w + kWalkBlockWords - 1u) / kWalkBlockWords;
+    const uint32_t n_blocks = (len_w + B - 1u) / B;
     if (n_blocks > blocks_max) bad = true;
-    BwBlock *my = info + slot * blocks_max;
+    BwBlock *my = info + pre[slot];
     uint32_t run = 0;
     for (uint32_t b0 = 0; b0 < n_blocks && !bad; b0 += 64) {
         const uint32_t b = b0 + (uint32_t)lane;
@@ -2212,10 +2254,13 @@ hipError_t launch_encode(const Geom &G, const int16_t *d_in, uint32_t *d_out, ui
 // long enough to outgrow the single pass's LDS buffer; in between the single pass is better
 // block-parallel walk of short waveforms: blocks per chunk at 25 bits per sample (0: the batch does not take it)
 uint32_t bw_walk_blocks_max(const Geom &G) {
-    // the two block passes cost ~15 us per chunk, the serial chase ~0.13 us per waveform of a chunk (all chunks at
-    // once) and large batches hide most of it: measured crossovers 150 chunks at L = 512, 80 at L = 2048
-    // (above WaveformLength 2048 the alternative is the scalar chain at 0.85 us per hop, 6.5x the LDS chase: W / 18)
-    const uint64_t per = G.u_wave_len <= kWalkShortLen ? 100u : 18u, cap = G.u_wave_len <= kWalkShortLen ? 150u : kPwMaxChunks;
+    // against the walk inside the decode launch (serial chase through LDS, 0.13 us per waveform of a chunk, all chunks at
+    // once, so that large batches hide most of it).  Measured crossovers (chunks of 14 M samples, decode GB/s of the two
+    // paths at 100 / 150 / 220 chunks): L = 512 1505 / 1557 / 1564 against 693 / 886 / 1224; L = 1024 1674 / 1727 / 1749
+    // against 990 / 1452 / 1889; L = 2048 1601 / 1659 / 1680 against 1393 / 1882 / 2243: about one chunk per 60
+    // waveforms of a chunk.  Above WaveformLength 2048 the alternative is the scalar chain at 0.85 us per hop (L = 3072:
+    // 1379 / 1431 / 1459 against 596 / 830 / 1123): W / 18
+    const uint64_t per = G.u_wave_len <= kWalkShortLen ? 60u : 18u, cap = kPwMaxChunks;
     const uint64_t limit = G.u_n_waves / per < cap ? G.u_n_waves / per : cap;
     // every 4096-word block must hold a header: n_i <= 25 L / 32 < 4096, i.e. L <= 5000; chunks of longer
     // waveforms within the chunk-wide walk's capacity take that one
@@ -2242,7 +2287,8 @@ uint64_t par_walk_scratch_bytes(const Geom &G) {
         bw_units = (uint64_t)G.n_short * G.rag_bw_blocks_max;
     }
     if (!pw && !bw) return 0;
-    return (pw ? G.n_chunks * kPwCap * sizeof(uint2) : 0) + (3u * G.n_chunks + 2u) * sizeof(uint32_t) + bw_units * sizeof(BwBlock);
+    return (pw ? G.n_chunks * kPwCap * sizeof(uint2) : 0) + (3u * G.n_chunks + 2u) * sizeof(uint32_t) +
+           bw_units * (kWalkBlockWords / 1024u) * sizeof(BwBlock);  // (blocks of 1024 words at the smallest)
 }
 
 bool long_batch(const Geom &G) {
@@ -2354,10 +2400,20 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                                                                                       d_wave_words, d_status, pw_fail);
             }
             if (use_bw) {
-                const uint64_t units = (uint64_t)n_bw * bwb;
-                k_bw_blocks<false><<<(unsigned)units, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, bw_list, n_bw, bwb, info, nullptr, nullptr, nullptr, d_status);
-                k_bw_scan<<<n_bw, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, bw_list, bwb, info, bw_fail);
-                k_bw_blocks<true><<<(unsigned)units, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, bw_list, n_bw, bwb, info, bw_fail, d_wave_off, d_wave_words, d_status);
+                // block size: the smallest that exceeds every listed chunk's max_words; wavefronts: what the LDS lets the chip hold
+                const uint32_t max_len = G.uniform ? G.u_wave_len : kWalkShortLen;
+                const uint32_t max_full = (uint32_t)(((uint64_t)max_len * 25u + 31u) >> 5);
+                auto run_bw = [&](auto btag, unsigned waves_per_cu) {
+                    constexpr uint32_t B = decltype(btag)::value;
+                    const uint32_t bmax = bwb * (kWalkBlockWords / B);
+                    const unsigned grid = 256u * waves_per_cu;
+                    k_bw_blocks<B, false><<<grid, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, bw_list, n_bw, bmax, info, nullptr, nullptr, nullptr, d_status);
+                    k_bw_scan<B><<<n_bw, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, bw_list, n_bw, bmax, info, bw_fail);
+                    k_bw_blocks<B, true><<<grid, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, bw_list, n_bw, bmax, info, bw_fail, d_wave_off, d_wave_words, d_status);
+                };
+                if (max_full + 2u <= 1024u) run_bw(std::integral_constant<uint32_t, 1024>{}, 24u);
+                else if (max_full + 2u <= 2048u) run_bw(std::integral_constant<uint32_t, 2048>{}, 13u);
+                else run_bw(std::integral_constant<uint32_t, 4096>{}, 7u);
                 k_walk_block_only<<<(unsigned)G.n_chunks, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_status, bw_fail);
             }
             if (impl == 5) impl = 1;

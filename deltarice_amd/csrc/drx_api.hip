@@ -25,6 +25,7 @@ struct drx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    SideStream side{nullptr, nullptr, nullptr};  // independent kernels of one call (launch_decode)
     int decode_impl = 8;   // launch_decode(): 8 = walk fused into the staged kernel, two samples per ring access
                            // (default), 7 = the same with a separate walk kernel, 5 / 1 = one sample per ring access
                            // (fused / separate walk), 0 = simple kernel
@@ -182,6 +183,15 @@ drx_status drx_ctx_create(int device, void *hip_stream, drx_ctx **out) {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return DRX_ERR_DEVICE; }
         c->own_stream = true;
     }
+    // the side stream is an optimisation: a context without one runs everything on its stream
+    if (hipStreamCreateWithFlags(&c->side.s, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->side.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->side.join, hipEventDisableTiming) != hipSuccess) {
+        if (c->side.s) (void)hipStreamDestroy(c->side.s);
+        if (c->side.fork) (void)hipEventDestroy(c->side.fork);
+        c->side = SideStream{nullptr, nullptr, nullptr};
+        (void)hipGetLastError();
+    }
     *out = c;
     return DRX_OK;
 }
@@ -197,6 +207,9 @@ void drx_ctx_destroy(drx_ctx *c) {
     if (c->d_off) (void)hipFree(c->d_off);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    if (c->side.s) (void)hipStreamDestroy(c->side.s);
+    if (c->side.fork) (void)hipEventDestroy(c->side.fork);
+    if (c->side.join) (void)hipEventDestroy(c->side.join);
     delete c;
 }
 
@@ -542,7 +555,7 @@ static drx_status decode_launch(drx_plan *p, const uint32_t *d_in, uint64_t in_w
     // not take those paths)
     DRX_HIP(ctx, launch_decode(p->G, d_in, in_words, d_chunk_word_off, d_out, p->d_wave_off,
                                p->d_wave_words, p->d_scan, p->d_status,
-                               (tables_ready ? 100 : 0) + ctx->decode_impl, p->d_pw, p->d_blk,
+                               (tables_ready ? 100 : 0) + ctx->decode_impl, p->d_pw, p->d_blk, ctx->side.s ? &ctx->side : nullptr,
                                ctx->profile ? p->ev : nullptr, ctx->stream));
     p->ev_valid = ctx->profile != 0;
     p->last_was_encode = false;

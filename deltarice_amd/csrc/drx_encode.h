@@ -59,14 +59,13 @@ __device__ __forceinline__ void packed_codes(const uint32_t x[4], uint32_t xprev
     for (int j = 0; j < 4; ++j) e[j] = qc[j] >> (uint16_t)3;                                         // 1 = escape (:215)
 #pragma unroll
     for (int j = 0; j < 4; ++j) c.nb[j] = as_u32(e[j] * c16k + (qc[j] + kp1));   // q+1+k, or 8+1+16
-    u16x2 r[4], one[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) r[j] = z[j] & (e[j] * mdelta + mlo);             // z & (M-1), or z
-#pragma unroll
-    for (int j = 0; j < 4; ++j) one[j] = (e[j] ^ splat(1u)) << kv;               // 1 << k, or 0 (bit 16 is c.e)
+    // c16 = z & (M-1) | M, or z for an escape: one v_bfi_b32 per dword, mask = M-1 or 0xffff per half (bit k of the
+    // word 1 << k lies outside M-1, and an escape's mask lets nothing of it through)
+    const uint32_t mword = as_u32(splat(1u << k));
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        c.c16[j] = as_u32(r[j] | one[j]);
+        const uint32_t mask = as_u32(e[j] * mdelta + mlo);
+        c.c16[j] = (mask & as_u32(z[j])) | (~mask & mword);
         c.e[j] = as_u32(e[j]);
     }
 }

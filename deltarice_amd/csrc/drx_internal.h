@@ -94,10 +94,15 @@ hipError_t launch_encode_long(const Geom &G, const int16_t *d_in, uint32_t *d_ou
                               uint64_t *d_chunk_words, uint32_t *d_seg_bits, uint64_t *d_seg_pos, DevStatus *d_status,
                               hipEvent_t *ev, hipStream_t s);
 
+// a second stream of the context, for kernels of one call that do not depend on each other (fork / join through events)
+struct SideStream {
+    hipStream_t s;
+    hipEvent_t fork, join;
+};
 hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                          const uint64_t *d_chunk_word_off, int16_t *d_out, uint64_t *d_wave_off,
                          uint32_t *d_wave_words, uint64_t *d_granules, DevStatus *d_status, int impl,
-                         void *d_pw, void *d_blk, hipEvent_t *ev, hipStream_t s);
+                         void *d_pw, void *d_blk, const SideStream *side, hipEvent_t *ev, hipStream_t s);
 // block-parallel decoder for batches of few waveforms (drx_blocks.hip): a workgroup per block of a waveform's stream
 bool blocks_batch(const Geom &G);
 uint64_t blocks_scratch_bytes(const Geom &G);

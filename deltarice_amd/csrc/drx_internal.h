@@ -64,6 +64,7 @@ struct Geom {
     uint32_t rag_groups;
     // ragged batches the pieces encoder takes (drx_pieces.hip): first workgroup of every chunk, n_chunks + 1 entries
     const uint32_t *pc_wg_base;
+    uint32_t pc_super;  // ... and every chunk's WaveformLength is above kPcMaxLen (waveforms over several workgroups)
 };
 
 struct DevStatus {
@@ -119,31 +120,44 @@ constexpr uint32_t kPcWholeLen = 10240;   // WaveformLengths up to here stay who
 constexpr uint32_t kPcMinLen = 64, kPcMaxLen = kPcSegSamples * kPcWaves;  // WaveformLengths it takes
 struct PieceShape {
     uint32_t run;      // waveforms per piece (> 1: runs of short waveforms)
-    uint32_t segs;     // pieces per waveform (a power of two <= kPcWaves; > 1: long waveforms)
+    uint32_t segs;     // pieces per waveform and workgroup (a power of two <= kPcWaves; > 1: long waveforms)
+    uint32_t parts;    // workgroups per waveform (> 1: waveforms longer than kPcMaxLen, kPcWaves segments per workgroup)
     uint32_t seg_len;  // samples per segment (a multiple of 512)
     uint32_t pieces;   // of the chunk
     uint32_t wgs;      // workgroups of the chunk
 };
 __host__ __device__ inline PieceShape piece_shape(uint32_t L, uint32_t W) {
     PieceShape s;
+    s.parts = 1u;
     if (L <= kPcRunSamples / 2u) {
         s.run = kPcRunSamples / L < kPcMaxRun ? kPcRunSamples / L : kPcMaxRun;
         s.segs = 1u;
         s.seg_len = L;
         s.pieces = (W + s.run - 1u) / s.run;
-    } else {
+        s.wgs = (s.pieces + kPcWaves - 1u) / kPcWaves;
+    } else if (L <= kPcMaxLen) {
         const uint32_t need = L <= kPcWholeLen ? 1u : (L + kPcSegSamples - 1u) / kPcSegSamples;
         s.run = 1u;
         s.segs = 1u;
         while (s.segs < need) s.segs <<= 1;
         s.seg_len = s.segs == 1u ? L : ((((L + s.segs - 1u) / s.segs) + 511u) & ~511u);
         s.pieces = W * s.segs;
+        s.wgs = (s.pieces + kPcWaves - 1u) / kPcWaves;
+    } else {
+        // a waveform over several workgroups ("parts"): kPcWaves segments each, as even as whole tiles allow
+        s.run = 1u;
+        s.segs = kPcWaves;
+        s.parts = (uint32_t)(((uint64_t)L + kPcMaxLen - 1u) / kPcMaxLen);
+        const uint32_t per_part = (uint32_t)(((uint64_t)L + s.parts - 1u) / s.parts);
+        s.seg_len = (((per_part + kPcWaves - 1u) / kPcWaves) + 511u) & ~511u;
+        s.pieces = 0u;  // (not used: every workgroup of the chunk is full)
+        s.wgs = W * s.parts;  // (the plan checks that this fits 31 bits)
     }
-    s.wgs = (s.pieces + kPcWaves - 1u) / kPcWaves;
     return s;
 }
 bool pieces_batch(const Geom &G);       // the batch takes this encoder
 uint64_t pieces_workgroups(const Geom &G, const ChunkDesc *host_chunks);
+uint64_t pieces_scan_words(const Geom &G, uint64_t total_wgs);  // uint64 words of its look-back state
 hipError_t launch_encode_pieces(const Geom &G, const int16_t *d_in, uint64_t in_samples, uint32_t *d_out, uint64_t out_cap,
                                 uint64_t *d_chunk_word_off, uint32_t *d_wave_words, uint64_t *d_scan, uint64_t total_wgs,
                                 DevStatus *d_status, hipEvent_t *ev, hipStream_t s);

@@ -13,6 +13,11 @@
 //            of every segment, segment s is copied out shifted to its bit position inside the waveform's stream, the word
 //            it shares with segment s + 1 completed from that wavefront's buffer (LDS, no global atomics, no zeroing);
 //   else     one waveform, as k_encode_fused.
+// SUPER (every WaveformLength above 65 536, among them the reference's default of one waveform per chunk): a waveform is
+// cut into PARTS of eight segments, a workgroup each.  The bits in front of a part come from a second look-back over the
+// parts of its waveform, the waveform's place from the first one, which then has one entry per WAVEFORM, published by
+// the waveform's last part.  The word a part shares with the next one is completed by its last wavefront, which codes
+// the 32 samples that follow its segment as well (at least 32 bits) -- so the parts exchange nothing but their bit counts.
 // The pieces of a chunk fill whole workgroups (a workgroup never spans two chunks), one ticket and one look-back entry
 // per workgroup as in k_encode_fused.  A piece whose code outgrows the 8 KB buffer (incompressible data) is coded again
 // after the look-back, tile by tile to its final position, by one wavefront per waveform.
@@ -73,21 +78,60 @@ __device__ __forceinline__ PcChunk pc_locate(const Geom &G, uint32_t T) {
     return q;
 }
 
+// Decoupled look-back, the reading half: sum of the values of entries [first, idx), 128 entries per poll.  Owners publish
+// kScanAgg | value, later kScanPrefix | sum of [first, own]; a zero entry is not there yet.  One wavefront calls this.
+__device__ __forceinline__ uint64_t lookback_sum(const uint64_t *state, int64_t idx, int64_t first, int lane, DevStatus *st) {
+    uint64_t sum = 0;
+    int64_t base = idx - 1;
+    uint32_t spins = 0;
+    for (;;) {
+        const int64_t i0 = base - lane, i1 = base - 64 - lane;
+        uint64_t s0v = kScanPrefix, s1v = kScanPrefix;  // in front of `first`: an empty prefix
+        if (i0 >= first) s0v = __hip_atomic_load(state + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (i1 >= first) s1v = __hip_atomic_load(state + i1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t st0 = (uint32_t)(s0v >> 62), st1 = (uint32_t)(s1v >> 62);
+        const uint64_t p0 = __ballot(st0 == 2u), z0 = __ballot(st0 == 0u);
+        const uint64_t p1 = __ballot(st1 == 2u), z1 = __ballot(st1 == 0u);
+        const int fp = p0 ? __builtin_ctzll(p0) : (p1 ? 64 + __builtin_ctzll(p1) : 128);
+        const uint64_t near0 = fp >= 64 ? ~0ull : ((1ull << fp) - 1ull);
+        const uint64_t near1 = fp >= 128 ? ~0ull : (fp > 64 ? ((1ull << (fp - 64)) - 1ull) : 0ull);
+        if ((z0 & near0) | (z1 & near1)) {  // a nearer predecessor has not published yet
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 22)) {  // cannot happen with zeroed state (ticket holders' predecessors run); never hang the GPU
+                if (lane == 0) atomicOr(&st->err, kErrInternal);
+                break;
+            }
+            continue;
+        }
+        const uint64_t c0 = (lane <= fp) ? (s0v & kScanValMask) : 0ull;
+        const uint64_t c1 = (64 + lane <= fp) ? (s1v & kScanValMask) : 0ull;
+        sum += wave_sum_u64(c0 + c1);
+        if (fp < 128) break;
+        base -= 128;
+    }
+    return sum;
+}
+
+__device__ __forceinline__ void scan_publish(uint64_t *state, int64_t idx, uint64_t tagged, int lane) {
+    if (lane == 0) __hip_atomic_store(state + idx, tagged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace
 
+template <bool SUPER>
 __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const int16_t *__restrict__ in, uint64_t in_samples,
                                                                  uint32_t *__restrict__ out, uint64_t out_cap,
                                                                  uint64_t *__restrict__ chunk_word_off,
                                                                  uint32_t *__restrict__ wave_words,
-                                                                 uint64_t *__restrict__ scan_state, uint32_t *__restrict__ ticket,
-                                                                 uint32_t total_wgs, DevStatus *st) {
+                                                                 uint64_t *__restrict__ scan_state, uint64_t *__restrict__ part_state,
+                                                                 uint32_t *__restrict__ ticket, uint32_t total_wgs, DevStatus *st) {
     // per wavefront: 4 pad words (place_words ORs zeros below a lane's first word), the code, 4 slack words
     __shared__ __attribute__((aligned(16))) uint32_t buf_all[kPcWaves][kEncCapWords + 8];
     __shared__ uint32_t s_ticket;
     __shared__ uint32_t s_n[kPcWaves][kPcMaxRun];  // runs: n_i of the run's waveforms
     __shared__ uint32_t s_size[kPcWaves];          // runs: words of the run, headers included; segments: bits of the segment
     __shared__ uint32_t s_fit[kPcWaves];           // the piece is in its buffer
-    __shared__ uint64_t s_excl;
+    __shared__ uint64_t s_excl, s_excl_bits, s_wf_words;
     const int lane = lane_id();
     const uint32_t wv = rfl(threadIdx.x >> 6);
     uint32_t *row = buf_all[wv];
@@ -104,29 +148,40 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
     q.sample_off = rfl64(q.sample_off); q.wave_base = rfl64(q.wave_base); q.c = rfl64(q.c);
     const PieceShape sh = piece_shape(q.L, q.W);
     const uint32_t p = rfl(q.j * kPcWaves + wv);  // piece of the chunk
-    const bool live = p < sh.pieces;
-    const bool runs = sh.run > 1u;
+    const bool live = SUPER || p < sh.pieces;
+    const bool runs = !SUPER && sh.run > 1u;
     const uint32_t S = sh.segs;
     const uint32_t k = G.k;
+    // SUPER: workgroup j of the chunk is part `part` of waveform w0, this wavefront its segment part * kPcWaves + wv
+    const uint32_t parts = SUPER ? sh.parts : 1u;
+    const uint32_t part = SUPER ? q.j % parts : 0u;
 
     // what this wavefront encodes: `nspans` spans of samples, contiguous in memory from x on
     //   runs:     span i = waveform w0 + i of the chunk (whole);        segments: one span = segment sg of waveform w0
-    const uint32_t w0 = runs ? p * sh.run : p / S;
-    const uint32_t sg = runs ? 0u : p % S;
+    //   SUPER:    a part's last wavefront takes a second span, the (up to) 32 samples behind its segment
+    const uint32_t w0 = SUPER ? q.j / parts : (runs ? p * sh.run : p / S);
+    const uint32_t sg = SUPER ? part * kPcWaves + wv : (runs ? 0u : p % S);
     uint32_t nspans = 0;
     uint32_t wf_len = 0;  // segments: samples of the whole waveform
+    uint32_t extra = 0;   // SUPER: samples of the second span
     if (live) {
         if (runs) {
             nspans = q.W - w0 < sh.run ? q.W - w0 : sh.run;
         } else {
             wf_len = (w0 + 1u == q.W) ? q.n_samples - w0 * q.L : q.L;
-            nspans = sg * sh.seg_len < wf_len ? 1u : 0u;
+            nspans = (uint64_t)sg * sh.seg_len < wf_len ? 1u : 0u;
+            if (SUPER && nspans && wv + 1u == kPcWaves && (uint64_t)(sg + 1u) * sh.seg_len < wf_len) {
+                const uint32_t left = wf_len - (sg + 1u) * sh.seg_len;
+                extra = left < 32u ? left : 32u;
+                nspans = 2u;
+            }
         }
     }
     const uint64_t wf_off = q.sample_off + (uint64_t)w0 * q.L;  // first sample of waveform w0 in the batch
     const uint64_t xoff = wf_off + (uint64_t)sg * sh.seg_len;   // first sample of this piece
     auto span_len = [&](uint32_t i) -> uint32_t {
         if (runs) return (w0 + i + 1u == q.W) ? q.n_samples - (w0 + i) * q.L : q.L;
+        if (SUPER && i == 1u) return extra;
         const uint32_t left = wf_len - sg * sh.seg_len;
         return left < sh.seg_len ? left : sh.seg_len;
     };
@@ -166,7 +221,8 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
     };
 
     uint32_t wpos = 0;   // runs: word of buf where the current waveform's header goes
-    uint32_t Pw = 0;     // bits of the current span so far
+    uint32_t Pw = 0;     // bits of the current span so far (SUPER: of both spans)
+    uint32_t seg_bits = 0;  // SUPER: bits of the segment itself
     bool fits = true;    // everything so far is in buf
     uint32_t carry = 0;  // dword whose high half is the sample before the tile
     auto process = [&](const Cursor &c, const uint4 &qv, auto full_tag) __attribute__((always_inline)) {
@@ -214,6 +270,7 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
                 Pw = 0;
                 carry = 0;  // the next waveform starts from x[-1] := 0
             }
+            if (SUPER && c.i == 0u) seg_bits = Pw;  // (what follows belongs to the next part)
         }
         cur_next(c);
     };
@@ -236,7 +293,7 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
     }
     wave_sync();
     if (lane == 0) {
-        s_size[wv] = runs ? wpos : Pw;
+        s_size[wv] = runs ? wpos : (SUPER ? seg_bits : Pw);
         s_fit[wv] = fits ? 1u : 0u;
     }
     __syncthreads();
@@ -276,59 +333,70 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
         }
     }
     const uint64_t block_sum = (uint64_t)block_words + (first_wg ? 1ull : 0ull);
+    // SUPER: the part's bits and whether all of it is in LDS
+    uint32_t part_bits = 0;
+    bool part_fit = true;
+    if (SUPER) {
+#pragma unroll
+        for (uint32_t i = 0; i < kPcWaves; ++i) { part_bits += s_size[i]; part_fit = part_fit && s_fit[i]; }
+    }
+    const bool last_part = part + 1u == parts;
+    const bool chunk_first = SUPER ? (w0 == 0u && part == 0u) : first_wg;
     if (wv == 0) {
-        uint64_t excl_blk = 0;
-        if (T == 0) {
-            if (lane == 0) __hip_atomic_store(scan_state + T, kScanPrefix | block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            // decoupled look-back over one entry per workgroup, 128 entries per poll (as in k_encode_fused)
-            if (lane == 0) __hip_atomic_store(scan_state + T, kScanAgg | block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int64_t base = (int64_t)T - 1;
-            uint32_t spins = 0;
-            for (;;) {
-                const int64_t i0 = base - lane, i1 = base - 64 - lane;
-                uint64_t s0v = kScanPrefix, s1v = kScanPrefix;
-                if (i0 >= 0) s0v = __hip_atomic_load(scan_state + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (i1 >= 0) s1v = __hip_atomic_load(scan_state + i1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t st0 = (uint32_t)(s0v >> 62), st1 = (uint32_t)(s1v >> 62);
-                const uint64_t p0 = __ballot(st0 == 2u), z0 = __ballot(st0 == 0u);
-                const uint64_t p1 = __ballot(st1 == 2u), z1 = __ballot(st1 == 0u);
-                const int fp = p0 ? __builtin_ctzll(p0) : (p1 ? 64 + __builtin_ctzll(p1) : 128);
-                const uint64_t near0 = fp >= 64 ? ~0ull : ((1ull << fp) - 1ull);
-                const uint64_t near1 = fp >= 128 ? ~0ull : (fp > 64 ? ((1ull << (fp - 64)) - 1ull) : 0ull);
-                if ((z0 & near0) | (z1 & near1)) {  // a nearer predecessor has not published yet
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 22)) {  // cannot happen with a zeroed scan_state; never hang the GPU
-                        if (lane == 0) atomicOr(&st->err, kErrInternal);
-                        break;
-                    }
-                    continue;
-                }
-                const uint64_t c0 = (lane <= fp) ? (s0v & kScanValMask) : 0ull;
-                const uint64_t c1 = (64 + lane <= fp) ? (s1v & kScanValMask) : 0ull;
-                excl_blk += wave_sum_u64(c0 + c1);
-                if (fp < 128) break;
-                base -= 128;
+        uint64_t excl_words = 0, sum_words = block_sum;
+        if (!SUPER) {
+            // decoupled look-back over one entry per workgroup (as in k_encode_fused)
+            if (T == 0) {
+                scan_publish(scan_state, T, kScanPrefix | block_sum, lane);
+            } else {
+                scan_publish(scan_state, T, kScanAgg | block_sum, lane);
+                excl_words = lookback_sum(scan_state, T, 0, lane, st);
+                scan_publish(scan_state, T, kScanPrefix | (excl_words + block_sum), lane);
             }
-            if (lane == 0)
-                __hip_atomic_store(scan_state + T, kScanPrefix | (excl_blk + block_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            // bits of the waveform in front of this part: look-back over the waveform's parts (workgroups T - part .. T)
+            uint64_t excl_bits = 0;
+            if (part == 0u) {
+                scan_publish(part_state, T, kScanPrefix | (uint64_t)part_bits, lane);
+            } else {
+                scan_publish(part_state, T, kScanAgg | (uint64_t)part_bits, lane);
+                excl_bits = lookback_sum(part_state, T, (int64_t)T - (int64_t)part, lane, st);
+                scan_publish(part_state, T, kScanPrefix | (excl_bits + part_bits), lane);
+            }
+            // words in front of the waveform: look-back over one entry per WAVEFORM, which its last part publishes
+            const int64_t U = (int64_t)(q.wave_base + w0);
+            const uint64_t n_total = (excl_bits + part_bits + 31u) >> 5;  // (last part: the waveform's payload words)
+            sum_words = 1ull + n_total + (w0 == 0u ? 1ull : 0ull);
+            if (last_part) {
+                if (U == 0) {
+                    scan_publish(scan_state, U, kScanPrefix | sum_words, lane);
+                } else {
+                    scan_publish(scan_state, U, kScanAgg | sum_words, lane);
+                    excl_words = lookback_sum(scan_state, U, 0, lane, st);
+                    scan_publish(scan_state, U, kScanPrefix | (excl_words + sum_words), lane);
+                }
+            } else if (U != 0) {
+                excl_words = lookback_sum(scan_state, U, 0, lane, st);
+            }
+            if (lane == 0) { s_excl_bits = excl_bits; s_wf_words = n_total; }
         }
         if (lane == 0) {
-            s_excl = excl_blk;
-            if (first_wg) {
-                chunk_word_off[q.c] = excl_blk;
-                if (excl_blk < out_cap) out[excl_blk] = q.n_samples;  // chunk header, src/deltaRice.c:415
+            s_excl = excl_words;
+            if (chunk_first) {
+                chunk_word_off[q.c] = excl_words;
+                if (excl_words < out_cap) out[excl_words] = q.n_samples;  // chunk header, src/deltaRice.c:415
             }
-            if (T + 1u == total_wgs) {
-                chunk_word_off[G.n_chunks] = excl_blk + block_sum;
-                st->total_words = excl_blk + block_sum;
-                if (excl_blk + block_sum > out_cap) atomicOr(&st->err, kErrCapacity);
+            if (T + 1u == total_wgs) {  // (SUPER: the last part of the last waveform)
+                chunk_word_off[G.n_chunks] = excl_words + sum_words;
+                st->total_words = excl_words + sum_words;
+                if (excl_words + sum_words > out_cap) atomicOr(&st->err, kErrCapacity);
             }
         }
     }
     __syncthreads();
     if (!live) return;
-    const uint64_t pos = s_excl + (first_wg ? 1ull : 0ull) + words_before;  // runs: first header of the run; segments: the waveform's header
+    // runs: first header of the run; segments: the waveform's header
+    const uint64_t pos = s_excl + ((SUPER ? w0 == 0u : first_wg) ? 1ull : 0ull) + words_before;
 
     // a waveform coded once more, tile by tile, straight to its place (its code did not fit the buffer)
     auto stream_waveform = [&](uint64_t soff, uint32_t len, uint32_t *__restrict__ outp) {
@@ -382,6 +450,83 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
         return;
     }
 
+    if (SUPER) {
+        uint32_t *__restrict__ outp = out + pos + 1u;
+        const uint64_t cap_words = out_cap > pos + 1u ? out_cap - pos - 1u : 0ull;  // payload words that still fit
+        if (last_part && wv == 0u && lane == 0) {
+            wave_words[q.wave_base + w0] = (uint32_t)s_wf_words;
+            if (pos < out_cap) out[pos] = (uint32_t)s_wf_words;  // src/deltaRice.c:379
+        }
+        uint32_t before = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < kPcWaves; ++i) before += i < wv ? s_size[i] : 0u;
+        if (!part_fit) {
+            // the part once more, tile by tile, by one wavefront: from bit s_excl_bits of the waveform's stream on; the
+            // word in which it starts belongs to the part in front, the one in which it ends is completed from the 32
+            // samples that follow
+            if (wv != 0u) return;
+            const uint64_t Bp = s_excl_bits;
+            const uint32_t P0 = (uint32_t)(Bp & 31u);
+            const uint64_t wbase = Bp >> 5;
+            const uint32_t limit = (P0 + part_bits + 31u) >> 5, skip = P0 ? 1u : 0u;  // words [skip, limit) from wbase are mine
+            const uint32_t s_begin = part * kPcWaves * sh.seg_len;
+            uint32_t s_end = s_begin + kPcWaves * sh.seg_len;
+            if (s_end > wf_len) s_end = wf_len;
+            const uint32_t more = wf_len - s_end < 32u ? wf_len - s_end : 32u;
+            const uint32_t len = s_end - s_begin + more;
+            for (int i = lane; i < (int)(kEncCapWords + 8) / 4; i += 64) reinterpret_cast<uint4 *>(row)[i] = make_uint4(0, 0, 0, 0);
+            wave_sync();
+            const int16_t *x = in + wf_off + s_begin;
+            uint64_t P = P0;
+            uint32_t cr = s_begin ? (uint32_t)(uint16_t)x[-1] << 16 : 0u;
+            const u16x2 tp[4] = {splat(1u), splat(0xffffu), splat(0u), splat(0u)};
+            for (uint32_t t0 = 0; t0 < len; t0 += kTile) {
+                uint32_t w[4];
+                const int nv = load8_dwords(x, len, t0, lane, true, w);
+                uint32_t xprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[3], 0x138, 0xf, 0xf, false);
+                if (lane == 0) xprev = cr;
+                cr = (uint32_t)__shfl((int)w[3], 63);
+                PackedCodes pc;
+                packed_codes<false>(w, xprev, 0u, tp, k, pc);
+                mask_tail(pc, nv);
+                const uint32_t lane_bits = lane_tile_bits(pc);
+                const uint32_t incl = wave_incl_scan_dpp(lane_bits);
+                const uint32_t tile_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                const uint64_t wfirst = P >> 5;  // first staged word
+                emit_tile<false>(pc, buf_bits + (uint32_t)(P & 31u) + incl - lane_bits);
+                P += tile_bits;
+                wave_sync();
+                const uint32_t nfull = (uint32_t)((P >> 5) - wfirst);
+                for (uint32_t i = lane; i < nfull; i += 64) {
+                    const uint64_t idx = wfirst + i;
+                    if (idx >= skip && idx < limit && wbase + idx < cap_words) outp[wbase + idx] = buf[i];
+                    buf[i] = 0;
+                }
+                wave_sync();
+                if (nfull && lane == 0) { const uint32_t cwd = buf[nfull]; buf[nfull] = 0; buf[0] = cwd; }
+                wave_sync();
+            }
+            const uint64_t idx = P >> 5;
+            if ((P & 31u) && lane == 0 && idx >= skip && idx < limit && wbase + idx < cap_words) outp[wbase + idx] = buf[0];
+            return;
+        }
+        // my words of the waveform's stream: those whose FIRST bit lies in my segment.  Bits behind my segment come from the
+        // next wavefront's buffer, or (last wavefront of the part) from the second span in my own
+        const uint32_t my_bits = s_size[wv];
+        const uint64_t B = s_excl_bits + before, E = B + my_bits;
+        const uint64_t w_lo = (B + 31u) >> 5, w_hi = (E + 31u) >> 5;
+        const uint32_t *nbuf = buf_all[(wv + 1u) & (kPcWaves - 1u)] + 4;
+        const bool has_next = wv + 1u < kPcWaves;
+        for (uint64_t w = w_lo + (uint32_t)lane; w < w_hi; w += 64u) {
+            const uint32_t o = (uint32_t)(32u * w - B), a = o >> 5, r = o & 31u;
+            uint32_t v = r ? __builtin_amdgcn_alignbit(buf[a], buf[a + 1u], 32u - r) : buf[a];
+            const uint32_t nb = (uint32_t)(E - 32u * w);  // my bits in this word from its top (>= 1)
+            if (nb < 32u && has_next) v |= nbuf[0] >> nb;
+            if (w < cap_words) outp[w] = v;
+        }
+        return;
+    }
+
     const uint32_t n = (grp_bits + 31u) >> 5;  // the waveform's payload words
     if (sg == 0u && lane == 0) wave_words[q.wave_base + w0] = n;
     if (pos + 1u + n > out_cap) return;
@@ -410,8 +555,9 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
 // k_encode_fused is bad at somewhere (a chunk of short or of long waveforms).  Measured against the segment encoder at 100 /
 // 5 / 1 chunks of 14 M samples (GB/s of int16): L = 512 2085 / 1374 / 669 against 973 / 592 / 220, L = 2048 2139 / 1494 / 664
 // against 1633 / 1125 / 482, L = 16 384 2299 / 1364 / 702 against 1791 / 1265 / 504, L = 65 536 2319 / 1400 / 669 against
-// 1629 / 1237 / 511 (profiles/r02_notes.md): no lower bound on the batch size.  Waveforms longer than kPcMaxLen (the
-// reference's default, one waveform per chunk) stay with the segment encoder, which cuts them into as many pieces as it likes.
+// 1629 / 1237 / 511 (profiles/r02_notes.md): no lower bound on the batch size.  A batch whose WaveformLengths are ALL above
+// kPcMaxLen (the reference's default, one waveform per chunk) takes the SUPER form; one that mixes the two kinds stays with
+// the segment encoder.
 // debug_flags: 4096 never this encoder, 8192 always the segment encoder, 32768 this encoder also where WaveformLength is in
 // k_encode_fused's own range (one waveform per wavefront; the tests compare the two that way).
 bool pieces_batch(const Geom &G) {
@@ -419,14 +565,16 @@ bool pieces_batch(const Geom &G) {
     const bool force = (G.dbg & 32768u) != 0;
     if (G.uniform) {
         const uint32_t L = G.u_wave_len;
-        if (L < kPcMinLen || L > kPcMaxLen) return false;
+        if (L < kPcMinLen) return false;
         if ((uint64_t)G.n_chunks * G.u_n_samples < (uint64_t)kTile) return false;
         const PieceShape sh = piece_shape(L, G.u_n_waves);
-        if ((uint64_t)sh.wgs * G.n_chunks > 0x7fffffffull) return false;
+        if ((uint64_t)G.u_n_waves * sh.parts > 0x7fffffffull || (uint64_t)sh.wgs * G.n_chunks > 0x7fffffffull) return false;
         return force || sh.run > 1u || sh.segs > 1u;
     }
     return G.pc_wg_base != nullptr;  // decided when the plan was made
 }
+
+static bool pieces_super(const Geom &G) { return G.uniform ? G.u_wave_len > kPcMaxLen : G.pc_super != 0; }
 
 uint64_t pieces_workgroups(const Geom &G, const ChunkDesc *host_chunks) {
     if (G.uniform) return (uint64_t)piece_shape(G.u_wave_len, G.u_n_waves).wgs * G.n_chunks;
@@ -435,18 +583,30 @@ uint64_t pieces_workgroups(const Geom &G, const ChunkDesc *host_chunks) {
     return t;
 }
 
+// look-back state: one entry per workgroup (SUPER: per waveform) | SUPER: one per workgroup for the parts | ticket
+uint64_t pieces_scan_words(const Geom &G, uint64_t total_wgs) {
+    return (pieces_super(G) ? G.total_waves + total_wgs : total_wgs) + 2u;
+}
+
 hipError_t launch_encode_pieces(const Geom &G, const int16_t *d_in, uint64_t in_samples, uint32_t *d_out, uint64_t out_cap,
                                 uint64_t *d_chunk_word_off, uint32_t *d_wave_words, uint64_t *d_scan, uint64_t total_wgs,
                                 DevStatus *d_status, hipEvent_t *ev, hipStream_t s) {
     if (G.total_waves == 0 || total_wgs == 0) return hipSuccess;
     if (ev) (void)hipEventRecord(ev[0], s);
-    // look-back entries (one per workgroup) + the ticket word behind them, zeroed on the stream before every launch
-    hipError_t e = hipMemsetAsync(d_scan, 0, (total_wgs + 2) * sizeof(uint64_t), s);
+    // zeroed on the stream before every launch (an entry is its own ready flag)
+    const uint64_t words = pieces_scan_words(G, total_wgs);
+    hipError_t e = hipMemsetAsync(d_scan, 0, words * sizeof(uint64_t), s);
     if (e != hipSuccess) return e;
     if (ev) { (void)hipEventRecord(ev[1], s); (void)hipEventRecord(ev[2], s); }
-    uint32_t *ticket = reinterpret_cast<uint32_t *>(d_scan + total_wgs);
-    k_encode_pieces<<<(unsigned)total_wgs, 64 * kPcWaves, 0, s>>>(G, d_in, in_samples, d_out, out_cap, d_chunk_word_off, d_wave_words,
-                                                                d_scan, ticket, (uint32_t)total_wgs, d_status);
+    uint32_t *ticket = reinterpret_cast<uint32_t *>(d_scan + words - 2u);
+    if (pieces_super(G))
+        k_encode_pieces<true><<<(unsigned)total_wgs, 64 * kPcWaves, 0, s>>>(G, d_in, in_samples, d_out, out_cap, d_chunk_word_off,
+                                                                          d_wave_words, d_scan, d_scan + G.total_waves, ticket,
+                                                                          (uint32_t)total_wgs, d_status);
+    else
+        k_encode_pieces<false><<<(unsigned)total_wgs, 64 * kPcWaves, 0, s>>>(G, d_in, in_samples, d_out, out_cap, d_chunk_word_off,
+                                                                           d_wave_words, d_scan, nullptr, ticket, (uint32_t)total_wgs,
+                                                                           d_status);
     if (ev) (void)hipEventRecord(ev[3], s);
     return hipGetLastError();
 }

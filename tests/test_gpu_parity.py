@@ -204,6 +204,18 @@ PIECE_CASES = [
     (2, 512 * 20, 512, 0, "zeros"),            # one bit per sample
     (2, 20000 * 2, 20000, 0, "zeros"),
     (3, 2000 * 10, 2000, 15, "uniform"),
+    # waveforms over several workgroups (WaveformLength above 65 536): parts of eight segments
+    (2, 70000 * 3 + 5000, 70000, 3, "gauss10"),    # two parts; a short leftover waveform
+    (3, 81920 * 2, 81920, 3, "gauss10"),           # the reference's nEDM shape (docs/Performance.md:27)
+    (1, 200000 * 2 + 65537, 200000, 3, "steps"),   # four parts; leftover of one part + 1 sample
+    (2, 300001, 0, 3, "gauss10"),                  # the reference's default: the chunk is one waveform
+    (1, 1 << 20, 0, 4, "gauss300"),
+    (2, 140000, 140000, 3, "uniform"),             # incompressible: parts coded again, from an unaligned bit on
+    (1, 131072 + 40, 131072, 3, "uniform"),        # ... with a second waveform of 40 samples
+    (2, 100000, 100000, 0, "zeros"),               # one bit per sample: 32 samples complete a shared word exactly
+    (2, 100000 * 2, 100000, 3, "zeros"),
+    (1, 65537 * 3, 65537, 3, "ramp"),
+    (1, 500000, 250000, 1, "gauss10"),
 ]
 
 
@@ -211,7 +223,7 @@ PIECE_CASES = [
 def test_pieces_encoder_vs_oracle(ctx, O, n_chunks, chunk_samples, L, k, kind):
     rng = np.random.default_rng(hash((n_chunks, chunk_samples, L, k)) & 0xFFFF)
     x = make_data(rng, kind, n_chunks * chunk_samples)
-    opts = (1 << k, L)
+    opts = (1 << k, L) if L else (1 << k,)
     ref_w, ref_off = O.encode_batch(x, chunk_samples, opts)
     plan = ctx.plan_uniform(n_chunks, chunk_samples, opts)
     ctx.set_option("debug_flags", 32768)
@@ -257,6 +269,32 @@ def test_pieces_encoder_ragged_and_capacity(ctx, O):
         assert np.array_equal(w2, w) and np.array_equal(off2, off)
     finally:
         ctx.set_option("debug_flags", 0)
+
+
+def test_pieces_encoder_ragged_long_waveforms(ctx, O):
+    """Ragged batches whose WaveformLengths are all above 65 536 take the pieces encoder's multi-workgroup form; one that
+    mixes them with shorter ones stays with the segment encoder.  Both must give the reference's bytes."""
+    rng = np.random.default_rng(78)
+    for Ls, Ns in (([70000, 0, 100000, 131072], [70000 * 2 + 9, 250000, 100000 * 3, 131072 + 131071]),
+                   ([70000, 512, 100000], [70000 * 2, 512 * 9, 100000])):
+        xs = [make_data(rng, "uniform" if c == 1 else "gauss10", n) for c, n in enumerate(Ns)]
+        x = np.concatenate(xs)
+        plan = ctx.plan(Ns, Ls, 8)
+        enc = plan.encode(dev(ctx, x))
+        w, off = enc.to_numpy()
+        at = 0
+        for c, (xc, L) in enumerate(zip(xs, Ls)):
+            ref = O.encode_chunk(xc, (8, L) if L else (8,))
+            assert off[c] == at
+            assert np.array_equal(w[at:at + ref.size], ref), f"chunk {c}"
+            at += ref.size
+        assert off[-1] == at == enc.total_words
+        assert np.array_equal(plan.decode(enc).cpu().numpy(), x)
+        import deltarice_amd as dr
+        for cap in (at - 1, at // 3):
+            with pytest.raises(dr.DeltaRiceError) as e:
+                plan.encode(dev(ctx, x), capacity_words=cap)
+            assert e.value.status == 3
 
 
 def test_decode_chunks_in_arbitrary_order(ctx, O):

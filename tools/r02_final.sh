@@ -3,7 +3,7 @@
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r02f; mkdir -p $O; cd $R
 timeout -k 10 600 python3 -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest_gpu.log
-timeout -k 10 400 python3 bench.py > $O/bench.log 2>&1; echo "bench rc=$?"; tail -1 $O/bench.log | cut -c1-1200
+bash tools/refresh_profiles.sh r02 2>&1 | tail -12; cp gpurun_out/refresh/r02_* $O/ 2>/dev/null
 gcc -O2 -Iinclude -I/opt/rocm/include tools/host_path_bench.c -o /tmp/host_path_bench -Ldeltarice_amd -ldeltarice_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$R/deltarice_amd -Wl,-rpath,/opt/rocm/lib -lm -D__HIP_PLATFORM_AMD__ \
   && timeout -k 10 300 /tmp/host_path_bench > $O/r02_host_path_bench_final.txt 2>&1; cat $O/r02_host_path_bench_final.txt
 HDF5=${HDF5_DIR:-/opt/conda}

@@ -1,7 +1,9 @@
 #!/bin/bash
 # Regenerates the artefacts under profiles/ from one GPU box: bench JSON, rocprofv3 kernel stats of the same
 # command, and the two PMC passes for HBM traffic.  Run from the repo root on the GPU box (gpurun).
+# usage: tools/refresh_profiles.sh [TAG]   (default r02; output in gpurun_out/refresh, to be copied into profiles/)
 set -e
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/refresh
@@ -10,10 +12,12 @@ cd $R
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats -o s --output-format csv -- python3 bench.py --cpu-seconds 0 > $O/stats.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_EA0_RDREQ_sum -d $O/pmc_rd -o p --output-format csv -- python3 bench.py --cpu-seconds 0 --steps 3 --warmup 1 > $O/pmc_rd.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum -d $O/pmc_wr -o p --output-format csv -- python3 bench.py --cpu-seconds 0 --steps 3 --warmup 1 > $O/pmc_wr.log 2>&1
-python3 profiles/make_traffic_json.py profiles/r01_pmc_traffic.json $O/pmc_rd/p_counter_collection.csv $O/pmc_wr/p_counter_collection.csv
-python3 profiles/trim_stats.py $O/stats/s_kernel_stats.csv $O/r01_kernel_stats.csv
-cp profiles/r01_pmc_traffic.json $O/r01_pmc_traffic.json
+DRX_TRAFFIC_SOURCE="rocprofv3 --pmc, python3 bench.py --cpu-seconds 0 --steps 3 --warmup 1, one MI355X" python3 profiles/make_traffic_json.py profiles/${TAG}_pmc_traffic.json $O/pmc_rd/p_counter_collection.csv $O/pmc_wr/p_counter_collection.csv
+python3 profiles/trim_stats.py $O/stats/s_kernel_stats.csv $O/${TAG}_kernel_stats.csv
+grep '^{"metric"' $O/stats.log | tail -1 > $O/${TAG}_bench_under_rocprof.json
+cp profiles/${TAG}_pmc_traffic.json $O/${TAG}_pmc_traffic.json
 timeout -k 10 400 python3 bench.py > $O/bench.log 2>&1
-tail -1 $O/bench.log > $O/r01_bench.json
-cat $O/r01_kernel_stats.csv | head -8
-tail -1 $O/bench.log
+tail -1 $O/bench.log > $O/${TAG}_bench.json
+rm -rf $O/stats $O/pmc_rd $O/pmc_wr
+cat $O/${TAG}_kernel_stats.csv | head -8
+tail -1 $O/bench.log | cut -c1-1500

@@ -99,9 +99,11 @@ def main():
                 opts = (1 << k, Ls[0]) + ((len(taps),) + tuple(t & 0xFFFFFFFF for t in taps) if taps else ())
                 plan = ctx.plan_uniform(n_chunks, Ns[0], opts)
             xd = dev(ctx, x)
-            for flags in (0, 256):
+            # (256: no long-waveform paths; 4096: no pieces encoder; 8192: the segment encoder; 32768: the pieces encoder
+            # wherever its geometry allows)
+            for flags in (0, 256, 4096, 8192, 32768):
                 ctx.set_option("debug_flags", flags)
-                for eimpl in (1, 0):
+                for eimpl in ((1, 0) if flags in (0, 256) else (1,)):
                     ctx.set_option("encode_impl", eimpl)
                     log(f"  encode flags {flags} impl {eimpl}")
                     w, off = plan.encode(xd).to_numpy()

@@ -381,6 +381,7 @@ drx_status drx_plan_create(drx_ctx *ctx, uint64_t n_chunks, const uint32_t *chun
         {
             bool ok = p->n_long <= kPwMaxChunks && p->n_short <= kPwMaxChunks;
             uint64_t bmax = 0;
+            uint32_t min_len = 0xffffffffu;
             for (uint64_t c = 0; c < n_chunks && ok; ++c) {
                 const ChunkDesc &d = desc[c];
                 if (d.wave_len > kWalkShortLenHost) {
@@ -389,10 +390,12 @@ drx_status drx_plan_create(drx_ctx *ctx, uint64_t n_chunks, const uint32_t *chun
                     ok = d.wave_len >= 16u && p->n_short <= d.n_waves / 60u;
                     const uint64_t mw = 1u + 2ull * d.n_waves + (((uint64_t)d.n_samples * 25u + 31u) >> 5);
                     bmax = std::max<uint64_t>(bmax, (mw + 4095u) / 4096u);
+                    min_len = std::min(min_len, d.wave_len);
                 }
             }
             p->G.rag_par = ok && bmax <= 0xfffffu;
             p->G.rag_bw_blocks_max = (uint32_t)bmax;
+            p->G.rag_bw_min_len = min_len;
         }
         // the segment encoder for ragged batches with short (<= 2048) or long (>= 16384) waveforms somewhere: unit
         // (waveform x 8192-sample segment slot) numbering per chunk

@@ -58,6 +58,7 @@ struct Geom {
     // ragged batches small enough for the parallel header walks (drx_kernels.hip): set when the plan is made;
     // rag_bw_blocks_max = 4096-word blocks of the largest short-waveform chunk at 25 bits per sample
     uint32_t rag_par, rag_bw_blocks_max;
+    uint32_t rag_bw_min_len;  // ... and the smallest WaveformLength among those chunks (bounds the headers of a block)
     // ragged batches, lane-per-waveform decode outside the fused launch: {chunk, group of 64 waveforms} of every
     // wavefront, longest WaveformLength first; rag_groups entries
     const uint2 *rag_order;

@@ -1295,7 +1295,7 @@ __global__ __launch_bounds__(64) void k_bw_blocks(Geom G, const uint32_t *__rest
                                                   uint32_t n_list, uint32_t blocks_max,
                                                   BwBlock *__restrict__ info, const uint32_t *__restrict__ fail,
                                                   uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
-                                                  DevStatus *st) {
+                                                  DevStatus *st, uint32_t *__restrict__ hops, uint32_t hop_cap) {
     constexpr int NV = B / 256;
     __shared__ __attribute__((aligned(16))) uint32_t blk[B];
     __shared__ uint16_t hop[EMIT ? B / 2 : 2];  // header positions inside the block (a waveform has at least one payload word)
@@ -1323,6 +1323,7 @@ __global__ __launch_bounds__(64) void k_bw_blocks(Geom G, const uint32_t *__rest
         if (b0 >= len_w) continue;   // (only a chunk cut at the host's bound; flagged by k_bw_scan)
         const uint32_t blk_len = len_w - b0 < B ? len_w - b0 : B;
         const uint32_t max_full = (uint32_t)(((uint64_t)L * 25u + 31u) >> 5);
+        const uint32_t min_words = min_payload_words(L, G.k);
         // the block's words into LDS (a fixed grid of 16-byte quads relative to the block)
         {
             const uint64_t a0 = begin + b0;
@@ -1372,6 +1373,12 @@ __global__ __launch_bounds__(64) void k_bw_blocks(Geom G, const uint32_t *__rest
                     const uint32_t n = __builtin_amdgcn_readfirstlane(blk[rel]);
                     // (n == 0 is no waveform: at least one bit per sample; it also bounds the headers of a block by B / 2)
                     if (n - 1u >= max_full || (uint64_t)b0 + rel + 1u + n > len_w) { ok = false; break; }
+                    if (hops) {
+                        // the header list for k_bw_emit: {position in the block, n}.  Its capacity counts on at least 1 + k
+                        // bits per sample (min_words) for every waveform but the chunk's last, shorter one
+                        if ((n < min_words && b0 + rel + 1u + n != len_w) || cnt >= hop_cap) { ok = false; break; }
+                        if (lane == 0) hops[(uint64_t)unit * hop_cap + cnt] = rel | (n << 12);
+                    }
                     rel += n + 1u;
                     ++cnt;
                 }
@@ -1466,6 +1473,61 @@ __global__ __launch_bounds__(64) void k_bw_scan(Geom G, const uint32_t *__restri
     // the last waveform may be shorter: its header has a tighter bound than the blocks checked
     if (lane == 0) fail[c] = bad ? 1u : 0u;
     (void)L;
+}
+
+// Second pass where the first one left the header list (bw_hop_cap() != 0): a wavefront per block, striding over the real
+// blocks as above, copies {position, n} into the table at the index k_bw_scan gave the block.  No LDS, no second read of
+// the stream, no second chase (config 5: 0.185 -> 0.03 ms).
+template <uint32_t B>
+__global__ __launch_bounds__(256) void k_bw_emit(Geom G, uint64_t in_words, const uint64_t *__restrict__ chunk_word_off,
+                                                 const uint32_t *__restrict__ list, uint32_t n_list, uint32_t blocks_max,
+                                                 const BwBlock *__restrict__ info, const uint32_t *__restrict__ fail,
+                                                 const uint32_t *__restrict__ hops, uint32_t hop_cap,
+                                                 uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words, DevStatus *st) {
+    __shared__ uint32_t pre[kBwMaxList + 1];
+    const int lane = lane_id();
+    const uint32_t wv = threadIdx.x >> 6;
+    if (wv == 0) bw_block_prefix<B>(chunk_word_off, in_words, list, n_list, blocks_max, pre, lane);
+    __syncthreads();
+    const uint32_t total = pre[n_list];
+    for (uint32_t unit = blockIdx.x * 4u + wv; unit < total; unit += gridDim.x * 4u) {
+        uint32_t lo = 0, hi = n_list;  // invariant: pre[lo] <= unit < pre[hi]
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (pre[mid] <= unit) lo = mid; else hi = mid;
+        }
+        const uint32_t slot = lo, b = unit - pre[lo];
+        const uint64_t c = list ? (uint64_t)list[slot] : slot;
+        if (fail[c]) continue;
+        const BwBlock me = info[unit];
+        if (me.entry == 0xffffffffu) continue;  // a last block without a header (k_bw_scan)
+        uint32_t W, L, n_samples;
+        uint64_t wbase;
+        if (G.uniform) { W = G.u_n_waves; L = G.u_wave_len; n_samples = G.u_n_samples; wbase = c * W; }
+        else { const ChunkDesc d = G.chunks[c]; W = d.n_waves; L = d.wave_len; n_samples = d.n_samples; wbase = d.wave_base; }
+        const uint64_t at = chunk_word_off[c] + (uint64_t)b * B;
+        for (uint32_t i = (uint32_t)lane; i < me.count; i += 64u) {
+            const uint32_t h = hops[(uint64_t)unit * hop_cap + i], pos = h & 0xfffu, n = h >> 12, wi = me.base + i;
+            wave_off[wbase + wi] = at + pos;
+            wave_words[wbase + wi] = n;
+            // the chunk's last waveform may be shorter than the rest: its header has tighter bounds (the others were held
+            // to [min, max] by the chase)
+            if (wi + 1u == W) {
+                const uint32_t last_len = n_samples - (W - 1u) * L;
+                if (n > max_payload_words(last_len) || n < min_payload_words(last_len, G.k)) atomicOr(&st->err, kErrCorrupt);
+            }
+        }
+    }
+}
+
+// capacity of a block's header list (0: the batch keeps the second chase): B-word blocks hold at most B / (min_words + 1)
+// headers + the chunk's last.  Waveforms of fewer than 32 words keep the second chase: one lane's store per header costs
+// more than it saves there (100 chunks of 14 M samples, walk with lists / with the second chase: L = 64 2.85 / 2.44 ms,
+// 128 1.59 / 1.44, 512 0.64 / 0.73, 1024 0.48 / 0.64, 2048 0.45 / 0.68, 3072 0.55 / 0.97)
+__host__ inline uint32_t bw_hop_cap(uint32_t B, uint32_t min_len, uint32_t k) {
+    const uint32_t mw = min_payload_words(min_len, k);
+    if (mw < 32u || B > 4096u) return 0u;
+    return B / (mw + 1u) + 2u;
 }
 
 __global__ __launch_bounds__(64) void k_walk_block_only(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
@@ -2271,6 +2333,14 @@ uint32_t bw_walk_blocks_max(const Geom &G) {
     return nb > 0xfffffu ? 0u : (uint32_t)nb;
 }
 
+// bytes of header list per 4096 words of stream for the block size the launch will choose (0: none kept)
+static uint64_t bw_hop_bytes_per_block4096(const Geom &G) {
+    const uint32_t max_len = G.uniform ? G.u_wave_len : kWalkShortLen, min_len = G.uniform ? G.u_wave_len : G.rag_bw_min_len;
+    const uint32_t max_full = (uint32_t)(((uint64_t)max_len * 25u + 31u) >> 5);
+    const uint32_t B = max_full + 2u <= 1024u ? 1024u : (max_full + 2u <= 2048u ? 2048u : 4096u);
+    return (uint64_t)bw_hop_cap(B, min_len, G.k) * sizeof(uint32_t) * (kWalkBlockWords / B);
+}
+
 // scratch of the parallel header walks (0: the batch takes neither); layout in launch_decode()
 uint64_t par_walk_scratch_bytes(const Geom &G) {
     bool pw, bw;
@@ -2288,7 +2358,8 @@ uint64_t par_walk_scratch_bytes(const Geom &G) {
     }
     if (!pw && !bw) return 0;
     return (pw ? G.n_chunks * kPwCap * sizeof(uint2) : 0) + (3u * G.n_chunks + 2u) * sizeof(uint32_t) +
-           bw_units * (kWalkBlockWords / 1024u) * sizeof(BwBlock);  // (blocks of 1024 words at the smallest)
+           bw_units * (kWalkBlockWords / 1024u) * sizeof(BwBlock) +  // (blocks of 1024 words at the smallest)
+           bw_units * bw_hop_bytes_per_block4096(G);                 // header lists of the first block pass
 }
 
 bool long_batch(const Geom &G) {
@@ -2412,13 +2483,20 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                 // block size: the smallest that exceeds every listed chunk's max_words; wavefronts: what the LDS lets the chip hold
                 const uint32_t max_len = G.uniform ? G.u_wave_len : kWalkShortLen;
                 const uint32_t max_full = (uint32_t)(((uint64_t)max_len * 25u + 31u) >> 5);
+                const uint32_t min_len = G.uniform ? G.u_wave_len : G.rag_bw_min_len;
                 auto run_bw = [&](auto btag, unsigned waves_per_cu) {
                     constexpr uint32_t B = decltype(btag)::value;
                     const uint32_t bmax = bwb * (kWalkBlockWords / B);
                     const unsigned grid = 256u * waves_per_cu;
-                    k_bw_blocks<B, false><<<grid, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, bw_list, n_bw, bmax, info, nullptr, nullptr, nullptr, d_status);
+                    // header lists behind info[] (sized for the smallest block: par_walk_scratch_bytes())
+                    const uint32_t hop_cap = bw_hop_cap(B, min_len, G.k);
+                    uint32_t *hops = hop_cap ? reinterpret_cast<uint32_t *>(info + (uint64_t)n_bw * bwb * (kWalkBlockWords / 1024u)) : nullptr;
+                    k_bw_blocks<B, false><<<grid, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, bw_list, n_bw, bmax, info, nullptr, nullptr, nullptr, d_status, hops, hop_cap);
                     k_bw_scan<B><<<n_bw, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, bw_list, n_bw, bmax, info, bw_fail);
-                    k_bw_blocks<B, true><<<grid, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, bw_list, n_bw, bmax, info, bw_fail, d_wave_off, d_wave_words, d_status);
+                    if (hops)
+                        k_bw_emit<B><<<256u * 8u, 256, 0, s>>>(G, in_words, d_chunk_word_off, bw_list, n_bw, bmax, info, bw_fail, hops, hop_cap, d_wave_off, d_wave_words, d_status);
+                    else
+                        k_bw_blocks<B, true><<<grid, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, bw_list, n_bw, bmax, info, bw_fail, d_wave_off, d_wave_words, d_status, nullptr, 0u);
                 };
                 if (max_full + 2u <= 1024u) run_bw(std::integral_constant<uint32_t, 1024>{}, 24u);
                 else if (max_full + 2u <= 2048u) run_bw(std::integral_constant<uint32_t, 2048>{}, 13u);

@@ -387,7 +387,7 @@ drx_status drx_plan_create(drx_ctx *ctx, uint64_t n_chunks, const uint32_t *chun
                 if (d.wave_len > kWalkShortLenHost) {
                     ok = d.n_waves <= kPwMaxWaves;
                 } else {
-                    ok = d.wave_len >= 16u && p->n_short <= d.n_waves / 60u;
+                    ok = d.wave_len >= 16u && p->n_short <= d.n_waves / 35u;
                     const uint64_t mw = 1u + 2ull * d.n_waves + (((uint64_t)d.n_samples * 25u + 31u) >> 5);
                     bmax = std::max<uint64_t>(bmax, (mw + 4095u) / 4096u);
                     min_len = std::min(min_len, d.wave_len);

@@ -2317,12 +2317,11 @@ hipError_t launch_encode(const Geom &G, const int16_t *d_in, uint32_t *d_out, ui
 // block-parallel walk of short waveforms: blocks per chunk at 25 bits per sample (0: the batch does not take it)
 uint32_t bw_walk_blocks_max(const Geom &G) {
     // against the walk inside the decode launch (serial chase through LDS, 0.13 us per waveform of a chunk, all chunks at
-    // once, so that large batches hide most of it).  Measured crossovers (chunks of 14 M samples, decode GB/s of the two
-    // paths at 100 / 150 / 220 chunks): L = 512 1505 / 1557 / 1564 against 693 / 886 / 1224; L = 1024 1674 / 1727 / 1749
-    // against 990 / 1452 / 1889; L = 2048 1601 / 1659 / 1680 against 1393 / 1882 / 2243: about one chunk per 60
-    // waveforms of a chunk.  Above WaveformLength 2048 the alternative is the scalar chain at 0.85 us per hop (L = 3072:
-    // 1379 / 1431 / 1459 against 596 / 830 / 1123): W / 18
-    const uint64_t per = G.u_wave_len <= kWalkShortLen ? 60u : 18u, cap = kPwMaxChunks;
+    // once, so that large batches hide most of it).  Measured (chunks of 14 M samples, decode GB/s of the two paths at
+    // 150 / 220 chunks): L = 512 1602 / 1627 against 875 / 1265; L = 1024 1869 / 1927 against 1521 / 1954; L = 2048
+    // 1906 / 2012 against 1673 / 2169: about one chunk per 35 waveforms of a chunk.  Above WaveformLength 2048 the
+    // alternative is the scalar chain at 0.85 us per hop (L = 3072, 100 / 220 chunks: 1731 / 1459+ against 596 / 1123): W / 18
+    const uint64_t per = G.u_wave_len <= kWalkShortLen ? 35u : 18u, cap = kPwMaxChunks;
     const uint64_t limit = G.u_n_waves / per < cap ? G.u_n_waves / per : cap;
     // every 4096-word block must hold a header: n_i <= 25 L / 32 < 4096, i.e. L <= 5000; chunks of longer
     // waveforms within the chunk-wide walk's capacity take that one

@@ -938,25 +938,29 @@ __global__ __launch_bounds__(64) void k_walk_scalar_only(Geom G, const uint32_t 
 // Anything unexpected (too many candidates, a broken link, a chain that does not end at the chunk end) flags the
 // chunk, and the scalar-load walker walks -- and judges -- the flagged chunks afterwards.
 constexpr int kPwThreads = 1024;
-constexpr uint32_t kPwCap = 4096;      // candidates per chunk, a power of two (bitonic sort)
+constexpr uint32_t kPwCap = 4096;      // candidates per chunk
+constexpr uint32_t kPwMaxParts = 128;  // slices of a chunk (pw_parts())
+constexpr uint32_t kPwStride = kPwCap + kPwMaxParts;  // a chunk's scratch: its candidates, then {first, count} of every slice
 constexpr int kPwLevels = 12;
 // (kPwMaxWaves, kPwMaxChunks: drx_internal.h)
 
-constexpr uint32_t kPwParts = 16;  // workgroups that scan one chunk
+// workgroups that scan one chunk: enough of them to fill the chip when the chunks are few (one chunk of 2000 x 7000, what an
+// H5Z call brings: 128 instead of 16 took the walk from 0.113 to 0.070 ms, k_pw_scan itself 9 us)
+__host__ inline uint32_t pw_parts(uint32_t n_chunks) { return n_chunks <= 4u ? 128u : (n_chunks <= 32u ? 32u : 16u); }
 
 // 1. candidates of one slice of a chunk -> the chunk's list in global memory (cand: kPwCap x {pos, val} per chunk,
 //    cand_count: one counter per chunk, zeroed before the launch)
 __global__ __launch_bounds__(256) void k_pw_scan(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
                                                  const uint64_t *__restrict__ chunk_word_off, const uint32_t *__restrict__ list,
-                                                 uint2 *__restrict__ cand, uint32_t *__restrict__ cand_count) {
-    const uint64_t c = list ? (uint64_t)list[blockIdx.x / kPwParts] : blockIdx.x / kPwParts;  // scratch is indexed by chunk
-    const uint32_t part = blockIdx.x % kPwParts, tid = threadIdx.x;
+                                                 uint2 *__restrict__ cand, uint32_t *__restrict__ cand_count, uint32_t parts) {
+    const uint64_t c = list ? (uint64_t)list[blockIdx.x / parts] : blockIdx.x / parts;  // scratch is indexed by chunk
+    const uint32_t part = blockIdx.x % parts, tid = threadIdx.x;
     const uint64_t begin = chunk_word_off[c], end = chunk_word_off[c + 1];
     if (end > in_words || begin + 2 > end || end - begin > 0x7fffffffull) return;  // k_walk_parallel flags the chunk
     const uint32_t len_w = (uint32_t)(end - begin);
     const uint32_t wl = G.uniform ? G.u_wave_len : G.chunks[c].wave_len;
     const uint32_t max_full = (uint32_t)(((uint64_t)wl * 25u + 31u) >> 5);
-    uint2 *clist = cand + c * kPwCap;
+    uint2 *clist = cand + c * kPwStride;
     // the slice's candidates are collected in LDS and appended with ONE global atomic (2000 atomics on one counter
     // cost 0.2 ms: same-address atomics serialise in the L2)
     __shared__ uint2 s_list[kPwCap / 4];
@@ -975,7 +979,7 @@ __global__ __launch_bounds__(256) void k_pw_scan(Geom G, const uint32_t *__restr
     const uint32_t *q0 = in + begin - mis;  // words before `begin` are ignored by consider()
     const uint32_t n_quads = (len_w + mis + 3u) >> 2;
     const bool vec_ok = begin >= mis;
-    const uint32_t per = (n_quads + kPwParts - 1u) / kPwParts;
+    const uint32_t per = (n_quads + parts - 1u) / parts;
     const uint32_t q_lo = part * per, q_hi = (q_lo + per < n_quads) ? q_lo + per : n_quads;
     constexpr uint32_t U = 4;
     for (uint32_t qb = q_lo + tid; qb < q_hi; qb += 256u * U) {
@@ -1011,22 +1015,32 @@ __global__ __launch_bounds__(256) void k_pw_scan(Geom G, const uint32_t *__restr
         if (tid == 0) atomicAdd(cand_count + c, kPwCap);
         return;
     }
-    if (tid == 0) s_base = atomicAdd(cand_count + c, n_loc);
+    if (tid == 0) {
+        s_base = atomicAdd(cand_count + c, n_loc);
+        clist[kPwCap + part] = make_uint2(s_base, n_loc);  // k_walk_parallel puts the slices in order
+    }
     __syncthreads();
+    // written in position order inside the slice (rank by counting: a slice holds tens of candidates), so that
+    // k_walk_parallel needs no sort
     const uint32_t b0 = s_base;
-    for (uint32_t i = tid; i < n_loc; i += 256u)
-        if (b0 + i < kPwCap) clist[b0 + i] = s_list[i];
+    for (uint32_t i = tid; i < n_loc; i += 256u) {
+        const uint2 e = s_list[i];
+        uint32_t r = 0;
+        for (uint32_t j = 0; j < n_loc; ++j) r += s_list[j].x < e.x ? 1u : 0u;
+        if (b0 + r < kPwCap) clist[b0 + r] = e;
+    }
 }
 
 __global__ __launch_bounds__(kPwThreads) void k_walk_parallel(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
                                                               const uint64_t *__restrict__ chunk_word_off,
                                                               uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
                                                               uint32_t *__restrict__ fail, const uint32_t *__restrict__ list,
-                                                              const uint2 *__restrict__ cand, const uint32_t *__restrict__ cand_count) {
+                                                              const uint2 *__restrict__ cand, const uint32_t *__restrict__ cand_count,
+                                                              uint32_t parts) {
     __shared__ uint32_t pos[kPwCap];   // candidate positions relative to the chunk start; padding entries sort last
     __shared__ uint32_t val[kPwCap];
     __shared__ uint16_t up[kPwLevels][kPwCap];
-    __shared__ uint32_t s_bad, s_start;
+    __shared__ uint32_t s_bad, s_start, s_first[kPwMaxParts], s_pre[kPwMaxParts + 1];
     const uint32_t tid = threadIdx.x;
     const uint64_t c = list ? (uint64_t)list[blockIdx.x] : blockIdx.x;
     uint32_t W, L, N;
@@ -1046,31 +1060,38 @@ __global__ __launch_bounds__(kPwThreads) void k_walk_parallel(Geom G, const uint
     const uint32_t min_full = min_payload_words(L, G.k), min_last = min_payload_words(N - (W - 1) * L, G.k);
     const uint32_t nc = cand_count[c];
     if (nc > kPwCap - 2u || nc < W) { if (tid == 0) fail[c] = 1u; return; }
-    for (uint32_t i = tid; i < kPwCap; i += kPwThreads) {
-        const uint2 e = i < nc ? cand[c * kPwCap + i] : make_uint2(0xffffffffu, 0u);
+    // the candidates in position order: k_pw_scan's slices cover the chunk in order and each wrote its own in order, so the
+    // slices only have to be put one behind the other (a bitonic sort of 4096 did this before: 78 barrier-separated stages)
+    if (tid < 64u) {
+        uint32_t run = 0;
+        for (uint32_t s0 = 0; s0 < parts; s0 += 64u) {
+            const uint32_t sl = s0 + tid;
+            uint2 e = make_uint2(0u, 0u);
+            if (sl < parts) e = cand[c * kPwStride + kPwCap + sl];
+            const uint32_t incl = wave_incl_scan_dpp(e.y);
+            if (sl < parts) { s_first[sl] = e.x; s_pre[sl + 1u] = run + incl; }
+            run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        if (tid == 0) s_pre[0] = 0;
+    }
+    __syncthreads();
+    if (s_pre[parts] != nc) { if (tid == 0) fail[c] = 1u; return; }  // (cannot happen: the slices' counts add up to it)
+    uint32_t n_pad = 64u;  // the candidates and the two sentinel nodes
+    while (n_pad < nc + 2u) n_pad <<= 1;
+    for (uint32_t i = tid; i < n_pad; i += kPwThreads) {
+        uint2 e = make_uint2(0xffffffffu, 0u);
+        if (i < nc) {
+            uint32_t lo = 0, hi = parts;  // invariant: s_pre[lo] <= i < s_pre[hi]
+            while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (s_pre[mid] <= i) lo = mid; else hi = mid; }
+            e = cand[c * kPwStride + s_first[lo] + (i - s_pre[lo])];
+        }
         pos[i] = e.x;
         val[i] = e.y;
     }
     __syncthreads();
-    // sort by position (bitonic, kPwCap elements, two compare-exchanges per thread and stage)
-    for (uint32_t k2 = 2; k2 <= kPwCap; k2 <<= 1) {
-        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = tid; t < kPwCap / 2; t += kPwThreads) {
-                const uint32_t a = ((t & ~(j - 1u)) << 1) | (t & (j - 1u));  // index with bit log2(j) clear
-                const uint32_t b = a | j;
-                const bool asc = (a & k2) == 0;
-                const uint32_t pa = pos[a], pb = pos[b];
-                if ((pa > pb) == asc) {
-                    pos[a] = pb; pos[b] = pa;
-                    const uint32_t va = val[a]; val[a] = val[b]; val[b] = va;
-                }
-            }
-            __syncthreads();
-        }
-    }
     // 2. links.  Nodes nc (END) and nc + 1 (INVALID) point to themselves.
     const uint32_t END = nc, INV = nc + 1u;
-    for (uint32_t i = tid; i < kPwCap; i += kPwThreads) {
+    for (uint32_t i = tid; i < n_pad; i += kPwThreads) {
         uint32_t to = i;  // padding and the two sentinels: self loops
         if (i < nc) {
             const uint64_t target = (uint64_t)pos[i] + val[i] + 1u;
@@ -1090,7 +1111,7 @@ __global__ __launch_bounds__(kPwThreads) void k_walk_parallel(Geom G, const uint
     __syncthreads();
     // 3. binary lifting
     for (int k = 1; k < kPwLevels; ++k) {
-        for (uint32_t i = tid; i < kPwCap; i += kPwThreads) up[k][i] = up[k - 1][up[k - 1][i]];
+        for (uint32_t i = tid; i < n_pad; i += kPwThreads) up[k][i] = up[k - 1][up[k - 1][i]];
         __syncthreads();
     }
     const uint32_t start = s_start;
@@ -2356,7 +2377,7 @@ uint64_t par_walk_scratch_bytes(const Geom &G) {
         bw_units = (uint64_t)G.n_short * G.rag_bw_blocks_max;
     }
     if (!pw && !bw) return 0;
-    return (pw ? G.n_chunks * kPwCap * sizeof(uint2) : 0) + (3u * G.n_chunks + 2u) * sizeof(uint32_t) +
+    return (pw ? G.n_chunks * kPwStride * sizeof(uint2) : 0) + (3u * G.n_chunks + 2u) * sizeof(uint32_t) +
            bw_units * (kWalkBlockWords / 1024u) * sizeof(BwBlock) +  // (blocks of 1024 words at the smallest)
            bw_units * bw_hop_bytes_per_block4096(G);                 // header lists of the first block pass
 }
@@ -2457,7 +2478,7 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
             const uint32_t n_pw = G.uniform ? (uint32_t)G.n_chunks : G.n_long, n_bw = G.uniform ? (uint32_t)G.n_chunks : G.n_short;
             const uint32_t bwb = G.uniform ? bw_blocks_max : G.rag_bw_blocks_max;
             uint2 *cand = reinterpret_cast<uint2 *>(d_pw);
-            uint32_t *cnt = reinterpret_cast<uint32_t *>(cand + (use_pw ? G.n_chunks * kPwCap : 0));
+            uint32_t *cnt = reinterpret_cast<uint32_t *>(cand + (use_pw ? G.n_chunks * kPwStride : 0));
             uint32_t *pw_fail = cnt + G.n_chunks, *bw_fail = pw_fail + G.n_chunks;
             BwBlock *info = reinterpret_cast<BwBlock *>(bw_fail + G.n_chunks + (G.n_chunks & 1u));
             hipError_t e = hipMemsetAsync(cnt, 0, 3u * G.n_chunks * sizeof(uint32_t), s);
@@ -2471,9 +2492,9 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                 if ((e = hipStreamWaitEvent(side->s, side->fork, 0)) != hipSuccess) return e;
             }
             if (use_pw) {
-                k_pw_scan<<<(unsigned)(n_pw * kPwParts), 256, 0, spw>>>(G, d_in, in_words, d_chunk_word_off, pw_list, cand, cnt);
+                k_pw_scan<<<(unsigned)(n_pw * pw_parts(n_pw)), 256, 0, spw>>>(G, d_in, in_words, d_chunk_word_off, pw_list, cand, cnt, pw_parts(n_pw));
                 k_walk_parallel<<<n_pw, kPwThreads, 0, spw>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words,
-                                                              pw_fail, pw_list, cand, cnt);
+                                                              pw_fail, pw_list, cand, cnt, pw_parts(n_pw));
                 k_walk_scalar_only<<<blocks_for(G.n_chunks, kWalkChains), 64, 0, spw>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off,
                                                                                         d_wave_words, d_status, pw_fail);
             }

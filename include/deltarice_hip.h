@@ -154,7 +154,8 @@ drx_status drx_plan_last_timings(drx_plan *plan, float ms[4]);
  *                                                                                       the staged kernel does not take)
  *   "debug_flags"  dispatch overrides that force an alternative (still bit-exact) path, for tests and A/B timing:
  *        256 never the long-waveform paths, 512 long waveforms one workgroup each, 2048 never the parallel header walks,
- *        8192 always the segment encoder.  (Ablation switches inside the kernels exist only in -DDRX_ABLATION builds.) */
+ *        4096 never the pieces encoder, 8192 always the segment encoder, 32768 the pieces encoder also where one wavefront per
+ *        waveform is the default.  (Ablation switches inside the kernels exist only in -DDRX_ABLATION builds.) */
 drx_status drx_ctx_set_option(drx_ctx *ctx, const char *key, int64_t value);
 
 #ifdef __cplusplus

@@ -11,3 +11,5 @@ gcc -O2 tools/h5_filter_bench.c -o /tmp/h5_filter_bench -I$HDF5/include -L$HDF5/
   && HDF5_PLUGIN_PATH=$R/deltarice_amd/plugin timeout -k 10 300 /tmp/h5_filter_bench /dev/shm/drx_bench.h5 > $O/r02_h5_filter_bench_final.txt 2>&1; cat $O/r02_h5_filter_bench_final.txt; rm -f /dev/shm/drx_bench.h5
 for w in nab1 small20 small100; do timeout -k 10 200 python3 tools/workload.py $w 2>/dev/null >> $O/r02_small_batches_final.txt; done; cut -c1-400 $O/r02_small_batches_final.txt
 tools/profile_workloads.sh r02f config5 long25 nedm noptrex 2>&1 | grep -E '^\{|k_decode|k_seg|k_bw|k_pw' | cut -c1-330
+timeout -k 10 500 python3 tools/bench_configs.py 2>/dev/null > $O/r02_bench_configs.txt; cat $O/r02_bench_configs.txt
+timeout -k 10 300 python3 tools/h5_direct_bench.py 2>/dev/null > $O/r02_h5_direct_bench.txt; cat $O/r02_h5_direct_bench.txt

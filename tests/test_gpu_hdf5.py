@@ -143,6 +143,35 @@ def test_h5dump_sees_the_filter(h5tool, tmp_path):
     assert "FILTER_ID 32025" in out and "PARAMS { 8 7000 }" in out
 
 
+def test_h5repack_and_h5diff_through_the_plugin(h5tool, tmp_path):
+    """The HDF5 tools as callers: h5repack re-filters an existing file with `UD=32025,...` through the dynamically
+    loaded plugin, and back to no filter; h5diff (which reads through the plugin) finds no difference; the chunks h5repack
+    stored are the reference's bytes."""
+    from oracle import oracle as O
+    h5repack, h5diff = (os.path.join(HDF5_DIR, "bin", t) for t in ("h5repack", "h5diff"))
+    if not (os.path.exists(h5repack) and os.path.exists(h5diff)):
+        pytest.skip("no h5repack / h5diff")
+    x = np.random.default_rng(3).normal(0, 10, (60, 1024)).astype(np.int16)
+    raw, plain, packed, back = (tmp_path / n for n in ("raw.bin", "plain.h5", "packed.h5", "back.h5"))
+    x.tofile(raw)
+    env = dict(os.environ, HDF5_PLUGIN_PATH=os.path.join(ROOT, "deltarice_amd", "plugin"))
+    # an unfiltered, chunked file (filter 32025 with the tool's write mode would already go through the plugin)
+    h5tool("write", plain, raw, 60, 1024, 20, 8, 1024)
+    subprocess.run([h5repack, "-f", "NONE", str(plain), str(back)], env=env, check=True, capture_output=True)
+    r = subprocess.run([h5repack, "-f", "test:UD=32025,0,2,16,1024", str(back), str(packed)], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = subprocess.run([os.path.join(HDF5_DIR, "bin", "h5dump"), "-pH", str(packed)], env=env, capture_output=True, text=True,
+                         check=True).stdout
+    assert "FILTER_ID 32025" in out and "PARAMS { 16 1024 }" in out
+    d = subprocess.run([h5diff, str(back), str(packed)], env=env, capture_output=True, text=True)
+    assert d.returncode == 0, d.stdout[-2000:] + d.stderr[-2000:]
+    n = int(h5tool("chunks", packed, tmp_path / "chunk").stdout)
+    assert n == 3
+    for i in range(n):
+        stored = np.fromfile(f"{tmp_path}/chunk.{i}", np.uint32)
+        assert np.array_equal(stored, O.encode_chunk(x[20 * i:20 * i + 20], (16, 1024))), f"chunk {i}"
+
+
 def test_explicit_registration_through_python_module(tmp_path):
     # counterpart of `import deltaRice.h5` (src/h5.pyx:55-61): explicit H5Zregister in a given libhdf5
     import ctypes as C

@@ -578,15 +578,6 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-// Which batches take this decoder: uniform, delta filter, and fewer waveforms than a quarter of the lanes of the chip.
-// Measured crossover against k_decode_lanes (tools/len_sweep.py, profiles/r02_blocks_vs_lanes.txt): a lane decodes
-// ~17 samples per microsecond whatever else runs, so the lane kernel takes ~60 ns x WaveformLength until the chip is
-// full (98 304 lanes); this kernel decodes ~400 samples per nanosecond once it has a few hundred blocks: the two
-// meet near 24 000 waveforms for every WaveformLength from 4096 to 65 536.
-bool blocks_batch(const Geom &G) {
-    return G.uniform && G.n_taps == 0 && G.total_waves <= 24576u && G.u_wave_len >= 2048u;
-}
-
 static int blocks_nt(const Geom &G) {
     // lanes per block: a waveform of about (k + 3.5) bits per sample should fill most of its last block
 #ifdef DRX_BLK_FORCE_NT
@@ -594,6 +585,26 @@ static int blocks_nt(const Geom &G) {
 #endif
     const uint64_t typ_words = ((uint64_t)G.u_wave_len * (2u * G.k + 7u)) >> 6;
     return typ_words <= blk_words(64) ? 64 : (typ_words <= blk_words(128) ? 128 : 256);
+}
+
+// Which batches take this decoder: uniform, delta filter, and cheaper here than a lane per waveform.  The two costs
+// (tools/len_sweep.py, profiles/r02_blocks_vs_lanes.txt, r02_len_sweep_*): a lane decodes ~17 samples per microsecond
+// whatever else runs, so k_decode_lanes takes ~60 ns x WaveformLength per 98 304 waveforms; a block costs a workgroup 21 /
+// 28 / 41 us at 256 / 128 / 64 lanes, full or not, with 768 / 1536 / 3072 workgroups resident.  (Round 2's first rule, "at
+// most 24 576 waveforms", sent 25 chunks of 854 x 16 384 here: two blocks per waveform, the second a fifth full, 1.46 ms
+// where the lane kernel takes 0.98.)
+bool blocks_batch(const Geom &G) {
+    if (!(G.uniform && G.n_taps == 0 && G.total_waves <= 98304u && G.u_wave_len >= 2048u)) return false;
+    const int nt = blocks_nt(G);
+    const uint64_t typ_words = ((uint64_t)G.u_wave_len * (2u * G.k + 7u)) >> 6;
+    const uint64_t bpw = (typ_words + blk_words((uint32_t)nt) - 1u) / blk_words((uint32_t)nt);
+    const uint64_t resident = nt == 256 ? 768u : (nt == 128 ? 1536u : 3072u);
+    // (waveforms of one or two blocks pay the ticket's dependent loads -- ticket, table entry, image -- per block: 36 us measured
+    // at 256 lanes, 10 chunks of 1166 x 12 000 and of 854 x 16 384)
+    const double t_blk = (nt == 256 ? 21.0 : (nt == 128 ? 28.0 : 41.0)) * (bpw <= 2u ? 1.7 : 1.0);
+    const double blocks_us = (double)((G.total_waves * bpw + resident - 1u) / resident) * t_blk;
+    const double lanes_us = 0.06 * (double)G.u_wave_len * (double)((G.total_waves + 98303u) / 98304u);
+    return blocks_us < lanes_us;
 }
 
 static uint32_t blocks_slots_per_wave(const Geom &G) {  // blocks of a waveform at 25 bits per sample

@@ -1310,7 +1310,7 @@ __device__ __forceinline__ void bw_block_prefix(const uint64_t *__restrict__ chu
     wave_sync();
 }
 
-template <uint32_t B, bool EMIT>
+template <uint32_t B, bool EMIT, bool LIST = false>
 __global__ __launch_bounds__(64) void k_bw_blocks(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
                                                   const uint64_t *__restrict__ chunk_word_off, const uint32_t *__restrict__ list,
                                                   uint32_t n_list, uint32_t blocks_max,
@@ -1394,7 +1394,7 @@ __global__ __launch_bounds__(64) void k_bw_blocks(Geom G, const uint32_t *__rest
                     const uint32_t n = __builtin_amdgcn_readfirstlane(blk[rel]);
                     // (n == 0 is no waveform: at least one bit per sample; it also bounds the headers of a block by B / 2)
                     if (n - 1u >= max_full || (uint64_t)b0 + rel + 1u + n > len_w) { ok = false; break; }
-                    if (hops) {
+                    if (LIST) {
                         // the header list for k_bw_emit: {position in the block, n}.  Its capacity counts on at least 1 + k
                         // bits per sample (min_words) for every waveform but the chunk's last, shorter one
                         if ((n < min_words && b0 + rel + 1u + n != len_w) || cnt >= hop_cap) { ok = false; break; }
@@ -2511,7 +2511,10 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                     // header lists behind info[] (sized for the smallest block: par_walk_scratch_bytes())
                     const uint32_t hop_cap = bw_hop_cap(B, min_len, G.k);
                     uint32_t *hops = hop_cap ? reinterpret_cast<uint32_t *>(info + (uint64_t)n_bw * bwb * (kWalkBlockWords / 1024u)) : nullptr;
-                    k_bw_blocks<B, false><<<grid, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, bw_list, n_bw, bmax, info, nullptr, nullptr, nullptr, d_status, hops, hop_cap);
+                    if (hops)
+                        k_bw_blocks<B, false, true><<<grid, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, bw_list, n_bw, bmax, info, nullptr, nullptr, nullptr, d_status, hops, hop_cap);
+                    else
+                        k_bw_blocks<B, false><<<grid, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, bw_list, n_bw, bmax, info, nullptr, nullptr, nullptr, d_status, nullptr, 0u);
                     k_bw_scan<B><<<n_bw, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, bw_list, n_bw, bmax, info, bw_fail);
                     if (hops)
                         k_bw_emit<B><<<256u * 8u, 256, 0, s>>>(G, in_words, d_chunk_word_off, bw_list, n_bw, bmax, info, bw_fail, hops, hop_cap, d_wave_off, d_wave_words, d_status);

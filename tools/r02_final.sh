@@ -13,3 +13,4 @@ for w in nab1 small20 small100; do timeout -k 10 200 python3 tools/workload.py $
 tools/profile_workloads.sh r02f config5 long25 nedm noptrex 2>&1 | grep -E '^\{|k_decode|k_seg|k_bw|k_pw' | cut -c1-330
 timeout -k 10 500 python3 tools/bench_configs.py 2>/dev/null > $O/r02_bench_configs.txt; cat $O/r02_bench_configs.txt
 timeout -k 10 300 python3 tools/h5_direct_bench.py 2>/dev/null > $O/r02_h5_direct_bench.txt; cat $O/r02_h5_direct_bench.txt
+for ch in 25 100; do DRX_SWEEP_CHUNKS=$ch timeout -k 10 400 python3 tools/len_sweep.py 64 128 512 1024 2048 3072 3500 5000 7000 9000 12000 16384 32768 65536 81920 500000 2>/dev/null > $O/r02_len_sweep_${ch}chunks.txt; cat $O/r02_len_sweep_${ch}chunks.txt; done

@@ -118,7 +118,7 @@ __device__ __forceinline__ void scan_publish(uint64_t *state, int64_t idx, uint6
 
 }  // namespace
 
-template <bool SUPER>
+template <bool SUPER, bool GEN>
 __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const int16_t *__restrict__ in, uint64_t in_samples,
                                                                  uint32_t *__restrict__ out, uint64_t out_cap,
                                                                  uint64_t *__restrict__ chunk_word_off,
@@ -186,8 +186,17 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
         return left < sh.seg_len ? left : sh.seg_len;
     };
     // the sample in front of a segment (a waveform's first sample has none: x[-1] := 0, src/deltaRice.c:53-54)
-    uint32_t carry0 = 0;
-    if (!runs && sg && nspans) carry0 = (uint32_t)(uint16_t)in[xoff - 1u] << 16;
+    // (GEN, a forward filter of up to four taps, src/deltaRice.c:64-74: the three samples in front, as two dwords)
+    uint32_t carry0 = 0, carry2_0 = 0;
+    if (!runs && sg && nspans) {
+        carry0 = (uint32_t)(uint16_t)in[xoff - 1u] << 16;
+        if (GEN) {  // (a segment starts at least 512 samples into its waveform)
+            carry0 |= (uint32_t)(uint16_t)in[xoff - 2u];
+            carry2_0 = (uint32_t)(uint16_t)in[xoff - 4u] | ((uint32_t)(uint16_t)in[xoff - 3u] << 16);
+        }
+    }
+    const u16x2 tp[4] = {splat(GEN ? G.enc_t[0] : 1u), splat(GEN ? G.enc_t[1] : 0xffffu), splat(GEN ? G.enc_t[2] : 0u),
+                         splat(GEN ? G.enc_t[3] : 0u)};
 
     // ---- the tiles of all spans as one sequence: loads run kDepth tiles ahead, across span boundaries ----
     struct Cursor { uint32_t i, off, rem; };  // span, sample offset of the tile from xoff, samples of the span from this tile on
@@ -225,6 +234,7 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
     uint32_t seg_bits = 0;  // SUPER: bits of the segment itself
     bool fits = true;    // everything so far is in buf
     uint32_t carry = 0;  // dword whose high half is the sample before the tile
+    uint32_t carry2 = 0;  // GEN: the dword before that one
     auto process = [&](const Cursor &c, const uint4 &qv, auto full_tag) __attribute__((always_inline)) {
         constexpr bool FULLT = decltype(full_tag)::value;
         uint32_t w[4] = {qv.x, qv.y, qv.z, qv.w};
@@ -232,9 +242,14 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
         uint32_t xprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[3], 0x138, 0xf, 0xf, false);  // wave_shr:1
         if (lane == 0) xprev = carry;
         carry = (uint32_t)__builtin_amdgcn_readlane((int)w[3], 63);
+        uint32_t xprev2 = 0;
+        if (GEN) {
+            xprev2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[2], 0x138, 0xf, 0xf, false);  // wave_shr:1
+            if (lane == 0) xprev2 = carry2;
+            carry2 = (uint32_t)__builtin_amdgcn_readlane((int)w[2], 63);
+        }
         PackedCodes pc;
-        const u16x2 tp[4] = {splat(1u), splat(0xffffu), splat(0u), splat(0u)};
-        packed_codes<false>(w, xprev, 0u, tp, k, pc);
+        packed_codes<GEN>(w, xprev, xprev2, tp, k, pc);
         if (!FULLT) {
             const uint32_t l8 = 8u * (uint32_t)lane;
             const int nv = c.rem <= l8 ? 0 : (int)(c.rem - l8 < 8u ? c.rem - l8 : 8u);
@@ -269,6 +284,7 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
                 wpos += 1u + n;
                 Pw = 0;
                 carry = 0;  // the next waveform starts from x[-1] := 0
+                carry2 = 0;
             }
             if (SUPER && c.i == 0u) seg_bits = Pw;  // (what follows belongs to the next part)
         }
@@ -277,6 +293,7 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
     {
         constexpr int kDepth = 3;
         carry = carry0;
+        carry2 = carry2_0;
         Cursor pcur = cur_first(), lcur = pcur;
         uint4 qv[kDepth];
 #pragma unroll
@@ -404,16 +421,21 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
         wave_sync();
         const int16_t *x = in + soff;
         uint64_t P = 0;
-        uint32_t cr = 0;
-        const u16x2 tp[4] = {splat(1u), splat(0xffffu), splat(0u), splat(0u)};
+        uint32_t cr = 0, cr2 = 0;
         for (uint32_t t0 = 0; t0 < len; t0 += kTile) {
             uint32_t w[4];
             const int nv = load8_dwords(x, len, t0, lane, true, w);
             uint32_t xprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[3], 0x138, 0xf, 0xf, false);
             if (lane == 0) xprev = cr;
             cr = (uint32_t)__shfl((int)w[3], 63);
+            uint32_t xprev2 = 0;
+            if (GEN) {
+                xprev2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[2], 0x138, 0xf, 0xf, false);
+                if (lane == 0) xprev2 = cr2;
+                cr2 = (uint32_t)__shfl((int)w[2], 63);
+            }
             PackedCodes pc;
-            packed_codes<false>(w, xprev, 0u, tp, k, pc);
+            packed_codes<GEN>(w, xprev, xprev2, tp, k, pc);
             mask_tail(pc, nv);
             const uint32_t lane_bits = lane_tile_bits(pc);
             const uint32_t incl = wave_incl_scan_dpp(lane_bits);
@@ -478,16 +500,28 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
             wave_sync();
             const int16_t *x = in + wf_off + s_begin;
             uint64_t P = P0;
-            uint32_t cr = s_begin ? (uint32_t)(uint16_t)x[-1] << 16 : 0u;
-            const u16x2 tp[4] = {splat(1u), splat(0xffffu), splat(0u), splat(0u)};
+            uint32_t cr = 0, cr2 = 0;
+            if (s_begin) {
+                cr = (uint32_t)(uint16_t)x[-1] << 16;
+                if (GEN) {
+                    cr |= (uint32_t)(uint16_t)x[-2];
+                    cr2 = (uint32_t)(uint16_t)x[-4] | ((uint32_t)(uint16_t)x[-3] << 16);
+                }
+            }
             for (uint32_t t0 = 0; t0 < len; t0 += kTile) {
                 uint32_t w[4];
                 const int nv = load8_dwords(x, len, t0, lane, true, w);
                 uint32_t xprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[3], 0x138, 0xf, 0xf, false);
                 if (lane == 0) xprev = cr;
                 cr = (uint32_t)__shfl((int)w[3], 63);
+                uint32_t xprev2 = 0;
+                if (GEN) {
+                    xprev2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[2], 0x138, 0xf, 0xf, false);
+                    if (lane == 0) xprev2 = cr2;
+                    cr2 = (uint32_t)__shfl((int)w[2], 63);
+                }
                 PackedCodes pc;
-                packed_codes<false>(w, xprev, 0u, tp, k, pc);
+                packed_codes<GEN>(w, xprev, xprev2, tp, k, pc);
                 mask_tail(pc, nv);
                 const uint32_t lane_bits = lane_tile_bits(pc);
                 const uint32_t incl = wave_incl_scan_dpp(lane_bits);
@@ -551,7 +585,7 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
     }
 }
 
-// The batches this encoder takes: delta filter, every WaveformLength within [kPcMinLen, kPcMaxLen], and a shape
+// The batches this encoder takes: delta filter or a forward filter of up to four taps, every WaveformLength from kPcMinLen, and a shape
 // k_encode_fused is bad at somewhere (a chunk of short or of long waveforms).  Measured against the segment encoder at 100 /
 // 5 / 1 chunks of 14 M samples (GB/s of int16): L = 512 2085 / 1374 / 669 against 973 / 592 / 220, L = 2048 2139 / 1494 / 664
 // against 1633 / 1125 / 482, L = 16 384 2299 / 1364 / 702 against 1791 / 1265 / 504, L = 65 536 2319 / 1400 / 669 against
@@ -561,7 +595,7 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
 // debug_flags: 4096 never this encoder, 8192 always the segment encoder, 32768 this encoder also where WaveformLength is in
 // k_encode_fused's own range (one waveform per wavefront; the tests compare the two that way).
 bool pieces_batch(const Geom &G) {
-    if (G.n_taps || (G.dbg & (8192u | 4096u))) return false;
+    if ((G.n_taps && !G.enc_fast) || (G.dbg & (8192u | 4096u))) return false;  // delta, or a forward filter of up to four taps
     const bool force = (G.dbg & 32768u) != 0;
     if (G.uniform) {
         const uint32_t L = G.u_wave_len;
@@ -599,14 +633,17 @@ hipError_t launch_encode_pieces(const Geom &G, const int16_t *d_in, uint64_t in_
     if (e != hipSuccess) return e;
     if (ev) { (void)hipEventRecord(ev[1], s); (void)hipEventRecord(ev[2], s); }
     uint32_t *ticket = reinterpret_cast<uint32_t *>(d_scan + words - 2u);
-    if (pieces_super(G))
-        k_encode_pieces<true><<<(unsigned)total_wgs, 64 * kPcWaves, 0, s>>>(G, d_in, in_samples, d_out, out_cap, d_chunk_word_off,
-                                                                          d_wave_words, d_scan, d_scan + G.total_waves, ticket,
-                                                                          (uint32_t)total_wgs, d_status);
-    else
-        k_encode_pieces<false><<<(unsigned)total_wgs, 64 * kPcWaves, 0, s>>>(G, d_in, in_samples, d_out, out_cap, d_chunk_word_off,
-                                                                           d_wave_words, d_scan, nullptr, ticket, (uint32_t)total_wgs,
-                                                                           d_status);
+    auto go = [&](auto super_tag, auto gen_tag) {
+        constexpr bool SUPER = decltype(super_tag)::value, GEN = decltype(gen_tag)::value;
+        k_encode_pieces<SUPER, GEN><<<(unsigned)total_wgs, 64 * kPcWaves, 0, s>>>(
+            G, d_in, in_samples, d_out, out_cap, d_chunk_word_off, d_wave_words, d_scan, SUPER ? d_scan + G.total_waves : nullptr, ticket,
+            (uint32_t)total_wgs, d_status);
+    };
+    const bool sup = pieces_super(G), gen = G.n_taps != 0;
+    if (sup && gen) go(std::true_type{}, std::true_type{});
+    else if (sup) go(std::true_type{}, std::false_type{});
+    else if (gen) go(std::false_type{}, std::true_type{});
+    else go(std::false_type{}, std::false_type{});
     if (ev) (void)hipEventRecord(ev[3], s);
     return hipGetLastError();
 }

@@ -495,6 +495,31 @@ def test_general_prediction_filters_vs_oracle(ctx, O):
         ctx.set_option("decode_impl", 8)
 
 
+def test_general_filters_through_the_pieces_encoder(ctx, O):
+    """Forward filters of up to four taps with short and with long waveforms: runs, segments and multi-workgroup waveforms
+    of drx_pieces.hip (the history a filter needs crosses tile, segment and part boundaries, and stops at waveform
+    boundaries, src/deltaRice.c:64-74); incompressible data takes the coded-again paths."""
+    rng = np.random.default_rng(78)
+    for taps in [(1, -1, 1, -1), (-1, 3, -3, 1), (2, -1), (1, -2, 1)]:
+        for n_chunks, N, L, kind in [(2, 512 * 21 + 100, 512, "gauss10"), (2, 700 * 9, 700, "gauss300"), (1, 16384 * 3 + 999, 16384, "gauss10"),
+                                     (2, 70000 * 2 + 30000, 70000, "gauss10"), (1, 150000, 0, "steps"), (1, 2048 * 6, 2048, "uniform"),
+                                     (1, 20000 * 2, 20000, "uniform"), (1, 140000, 140000, "uniform")]:
+            x = make_data(rng, kind, n_chunks * N)
+            opts = (8, L if L else N, len(taps)) + tuple(t & 0xFFFFFFFF for t in taps)
+            ref_w, ref_off = O.encode_batch(x, N, opts)
+            plan = ctx.plan_uniform(n_chunks, N, opts)
+            for flags in (0, 32768, 4096):
+                ctx.set_option("debug_flags", flags)
+                enc = plan.encode(dev(ctx, x))
+                w, off = enc.to_numpy()
+                ctx.set_option("debug_flags", 0)
+                assert np.array_equal(off, ref_off) and np.array_equal(w, ref_w), (taps, L, kind, flags)
+            y = plan.decode(enc).cpu().numpy()
+            assert np.array_equal(y, O.decode_batch(ref_w, ref_off, N, opts)), (taps, L, kind)
+            if abs(taps[0]) == 1:
+                assert np.array_equal(y, x)
+
+
 def test_rice_parameter_optimiser_is_exact(ctx, O):
     rng = np.random.default_rng(31)
     x = (rng.standard_t(3, 4 * 6000) * 25).clip(-32768, 32767).astype(np.int16)

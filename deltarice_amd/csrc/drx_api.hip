@@ -298,9 +298,9 @@ static drx_status plan_alloc_scratch(drx_ctx *ctx, drx_plan *p) {
     if (const uint64_t nb = blocks_scratch_bytes(p->G)) DRX_HIP(ctx, hipMalloc(&p->d_blk, nb));
     if (p->G.uniform) {  // the pieces encoder's workgroups, where the geometry is one it can take (pieces_batch() decides per call)
         const uint32_t L = p->G.u_wave_len;
-        const PieceShape sh = piece_shape(L, p->G.u_n_waves);
+        const PieceShape sh = piece_shape(L, p->G.u_n_waves, piece_packable(L));
         const uint64_t wgs = (uint64_t)sh.wgs * p->G.n_chunks;
-        if (L >= kPcMinLen && (uint64_t)p->G.u_n_waves * sh.parts <= 0x7fffffffull && wgs <= 0x7fffffffull && p->total_samples >= 512u)
+        if ((L >= kPcMinLen || piece_packable(L)) && (uint64_t)p->G.u_n_waves * sh.parts <= 0x7fffffffull && wgs <= 0x7fffffffull && p->total_samples >= 512u)
             p->pc_wgs = wgs;
     }
     if (p->pc_wgs) DRX_HIP(ctx, hipMalloc((void **)&p->d_pc_scan, pieces_scan_words(p->G, p->pc_wgs) * sizeof(uint64_t)));
@@ -414,15 +414,16 @@ drx_status drx_plan_create(drx_ctx *ctx, uint64_t n_chunks, const uint32_t *chun
         // the pieces encoder (drx_pieces.hip): every WaveformLength within its range and some chunk of short or of long
         // waveforms -- or every WaveformLength above its range (waveforms over several workgroups); workgroup numbering per chunk
         {
-            bool ok = soff >= 512u, some = false, all_super = true, none_super = true;
+            bool ok = soff >= 512u, some = false, all_super = true, none_super = true, all_packed = true;
+            for (uint64_t c = 0; c < n_chunks; ++c) all_packed = all_packed && piece_packable(desc[c].wave_len);
             std::vector<uint32_t> wb(n_chunks + 1, 0);
             uint64_t wgs = 0;
             for (uint64_t c = 0; c < n_chunks && ok; ++c) {
-                const PieceShape sh = piece_shape(desc[c].wave_len, desc[c].n_waves);
-                ok = desc[c].wave_len >= kPcMinLen && (uint64_t)desc[c].n_waves * sh.parts <= 0x7fffffffull;
+                const PieceShape sh = piece_shape(desc[c].wave_len, desc[c].n_waves, all_packed);
+                ok = (all_packed || desc[c].wave_len >= kPcMinLen) && (uint64_t)desc[c].n_waves * sh.parts <= 0x7fffffffull;
                 all_super = all_super && sh.parts > 1u;
                 none_super = none_super && sh.parts == 1u;
-                some = some || sh.run > 1u || sh.segs > 1u;
+                some = some || all_packed || sh.run > 1u || sh.segs > 1u;
                 wgs += sh.wgs;
                 ok = ok && wgs <= 0x7fffffffull;
                 wb[c + 1] = (uint32_t)wgs;
@@ -432,6 +433,7 @@ drx_status drx_plan_create(drx_ctx *ctx, uint64_t n_chunks, const uint32_t *chun
                 if (e == hipSuccess) e = hipMemcpy(p->d_pc_wg_base, wb.data(), wb.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
                 p->G.pc_wg_base = p->d_pc_wg_base;
                 p->G.pc_super = all_super ? 1u : 0u;
+                p->G.pc_packed = all_packed ? 1u : 0u;
                 p->pc_wgs = wgs;
             }
         }

@@ -66,6 +66,7 @@ struct Geom {
     // ragged batches the pieces encoder takes (drx_pieces.hip): first workgroup of every chunk, n_chunks + 1 entries
     const uint32_t *pc_wg_base;
     uint32_t pc_super;  // ... and every chunk's WaveformLength is above kPcMaxLen (waveforms over several workgroups)
+    uint32_t pc_packed;  // ... or every chunk's WaveformLength is piece_packable()
 };
 
 struct DevStatus {
@@ -127,10 +128,21 @@ struct PieceShape {
     uint32_t pieces;   // of the chunk
     uint32_t wgs;      // workgroups of the chunk
 };
-__host__ __device__ inline PieceShape piece_shape(uint32_t L, uint32_t W) {
+// waveforms of fewer than 512 samples, a multiple of 8 (a lane's 8 samples never straddle two waveforms): PACKED runs, whose
+// tiles span waveform boundaries
+__host__ __device__ inline bool piece_packable(uint32_t L) { return L >= 8u && L < 512u && (L & 7u) == 0u; }
+__host__ __device__ inline PieceShape piece_shape(uint32_t L, uint32_t W, bool packed = false) {
     PieceShape s;
     s.parts = 1u;
-    if (L <= kPcRunSamples / 2u) {
+    if (packed) {
+        // as many waveforms as fill ~7000 samples AND leave the 2048-word buffer room at 9 bits per sample + a header each
+        const uint32_t by_samples = kPcRunSamples / L, by_words = 2000u / (1u + (9u * L + 31u) / 32u);
+        s.run = by_samples < by_words ? by_samples : by_words;
+        s.segs = 1u;
+        s.seg_len = L;
+        s.pieces = (W + s.run - 1u) / s.run;
+        s.wgs = (s.pieces + kPcWaves - 1u) / kPcWaves;
+    } else if (L <= kPcRunSamples / 2u) {
         s.run = kPcRunSamples / L < kPcMaxRun ? kPcRunSamples / L : kPcMaxRun;
         s.segs = 1u;
         s.seg_len = L;

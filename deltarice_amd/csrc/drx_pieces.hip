@@ -49,10 +49,10 @@ __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin
 __device__ __forceinline__ uint64_t rfl64(uint64_t v) { return ((uint64_t)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v); }
 
 // workgroup (ticket) T -> chunk
-__device__ __forceinline__ PcChunk pc_locate(const Geom &G, uint32_t T) {
+__device__ __forceinline__ PcChunk pc_locate(const Geom &G, uint32_t T, bool packed) {
     PcChunk q;
     if (G.uniform) {
-        const uint32_t wgs = piece_shape(G.u_wave_len, G.u_n_waves).wgs;
+        const uint32_t wgs = piece_shape(G.u_wave_len, G.u_n_waves, packed).wgs;
         q.c = T / wgs;
         q.j = T - (uint32_t)q.c * wgs;
         q.sample_off = q.c * (uint64_t)G.u_n_samples;
@@ -118,7 +118,7 @@ __device__ __forceinline__ void scan_publish(uint64_t *state, int64_t idx, uint6
 
 }  // namespace
 
-template <bool SUPER, bool GEN>
+template <bool SUPER, bool GEN, bool PACKED>
 __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const int16_t *__restrict__ in, uint64_t in_samples,
                                                                  uint32_t *__restrict__ out, uint64_t out_cap,
                                                                  uint64_t *__restrict__ chunk_word_off,
@@ -143,13 +143,13 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
     __syncthreads();
     const uint32_t T = s_ticket;
     if (T >= total_wgs) return;  // (the grid is exactly total_wgs workgroups)
-    PcChunk q = pc_locate(G, T);
+    PcChunk q = pc_locate(G, T, PACKED);
     q.n_samples = rfl(q.n_samples); q.L = rfl(q.L); q.W = rfl(q.W); q.j = rfl(q.j);
     q.sample_off = rfl64(q.sample_off); q.wave_base = rfl64(q.wave_base); q.c = rfl64(q.c);
-    const PieceShape sh = piece_shape(q.L, q.W);
+    const PieceShape sh = piece_shape(q.L, q.W, PACKED);
     const uint32_t p = rfl(q.j * kPcWaves + wv);  // piece of the chunk
     const bool live = SUPER || p < sh.pieces;
-    const bool runs = !SUPER && sh.run > 1u;
+    const bool runs = !SUPER && (PACKED || sh.run > 1u);
     const uint32_t S = sh.segs;
     const uint32_t k = G.k;
     // SUPER: workgroup j of the chunk is part `part` of waveform w0, this wavefront its segment part * kPcWaves + wv
@@ -164,9 +164,15 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
     uint32_t nspans = 0;
     uint32_t wf_len = 0;  // segments: samples of the whole waveform
     uint32_t extra = 0;   // SUPER: samples of the second span
+    uint32_t run_wfs = 0, run_samples = 0;  // PACKED: waveforms and samples of the run
     if (live) {
         if (runs) {
             nspans = q.W - w0 < sh.run ? q.W - w0 : sh.run;
+            if (PACKED) {  // the run's samples as ONE span: tiles span waveform boundaries
+                run_wfs = nspans;
+                run_samples = (w0 + nspans == q.W) ? q.n_samples - w0 * q.L : nspans * q.L;
+                nspans = 1u;
+            }
         } else {
             wf_len = (w0 + 1u == q.W) ? q.n_samples - w0 * q.L : q.L;
             nspans = (uint64_t)sg * sh.seg_len < wf_len ? 1u : 0u;
@@ -180,6 +186,7 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
     const uint64_t wf_off = q.sample_off + (uint64_t)w0 * q.L;  // first sample of waveform w0 in the batch
     const uint64_t xoff = wf_off + (uint64_t)sg * sh.seg_len;   // first sample of this piece
     auto span_len = [&](uint32_t i) -> uint32_t {
+        if (PACKED) return run_samples;
         if (runs) return (w0 + i + 1u == q.W) ? q.n_samples - (w0 + i) * q.L : q.L;
         if (SUPER && i == 1u) return extra;
         const uint32_t left = wf_len - sg * sh.seg_len;
@@ -232,6 +239,9 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
     uint32_t wpos = 0;   // runs: word of buf where the current waveform's header goes
     uint32_t Pw = 0;     // bits of the current span so far (SUPER: of both spans)
     uint32_t seg_bits = 0;  // SUPER: bits of the segment itself
+    uint32_t open_bits = 0;  // PACKED: bits so far of the waveform that is open where the tile begins (its header word: wpos)
+    uint32_t pk_wi = 0;
+    const uint32_t pk_magic = PACKED ? 0xffffffffu / q.L + 1u : 0u;
     bool fits = true;    // everything so far is in buf
     uint32_t carry = 0;  // dword whose high half is the sample before the tile
     uint32_t carry2 = 0;  // GEN: the dword before that one
@@ -248,6 +258,19 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
             if (lane == 0) xprev2 = carry2;
             carry2 = (uint32_t)__builtin_amdgcn_readlane((int)w[2], 63);
         }
+        // PACKED: which waveform of the run my 8 samples belong to (WaveformLength is a multiple of 8: all to one), whether
+        // they open or close it
+        uint32_t pk_g0 = 0, pk_wstart = 0;
+        bool pk_end = false, pk_in = false;
+        if (PACKED) {
+            pk_g0 = c.off + 8u * (uint32_t)lane;          // my first sample, counted from the run's
+            const uint32_t wi = __umulhi(pk_g0, pk_magic);  // = pk_g0 / L (exact: pk_g0 L < 2^32)
+            pk_wstart = wi * q.L;
+            pk_in = pk_g0 < run_samples;
+            pk_end = pk_in && (pk_g0 + 8u >= pk_wstart + q.L || pk_g0 + 8u >= run_samples);
+            if (pk_g0 == pk_wstart) { xprev = 0; xprev2 = 0; }  // a waveform starts from x[-1] := 0 (src/deltaRice.c:53-54)
+            pk_wi = wi;
+        }
         PackedCodes pc;
         packed_codes<GEN>(w, xprev, xprev2, tp, k, pc);
         if (!FULLT) {
@@ -260,6 +283,37 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
         if (FULLT) concat_codes(pc, cw);
         const uint32_t incl = wave_incl_scan_dpp(lane_bits);
         const uint32_t tile_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (PACKED) {
+            // bits of my waveform in front of me: those of this tile (a segmented scan through the lane that opens the
+            // waveform in this tile) + those of earlier tiles if it was open when the tile began
+            const uint32_t ex = incl - lane_bits;
+            const uint32_t s0 = pk_wstart <= c.off ? 0u : (pk_wstart - c.off) >> 3;  // first lane of my waveform in this tile
+            const uint32_t ex_s = (uint32_t)__shfl((int)ex, (int)s0);
+            const uint32_t my_bit = (pk_wstart < c.off ? open_bits : 0u) + ex - ex_s;
+            const uint32_t n_w = (my_bit + lane_bits + 31u) >> 5;  // (of a lane that closes its waveform: n_i)
+            const uint32_t wscan = wave_incl_scan_dpp(pk_end ? 1u + n_w : 0u);
+            // words of the waveforms closed before mine (the shuffle outside any branch: it reads active lanes only)
+            const uint32_t wprev = (uint32_t)__shfl((int)wscan, (int)((s0 - 1u) & 63u));
+            const uint32_t before = s0 ? wprev : 0u;
+            const uint32_t wpos_my = wpos + before;  // my waveform's header word
+            // (a lane behind the run's end codes nothing; its position only has to lie inside the buffer)
+            const uint32_t P_lane = pk_in ? 32u * (wpos_my + 1u) + my_bit : 32u * (wpos + 1u);
+            const uint32_t done_words = (uint32_t)__builtin_amdgcn_readlane((int)wscan, 63);
+            const uint32_t open_new = (uint32_t)__builtin_amdgcn_readlane((int)((pk_end || !pk_in) ? 0u : my_bit + lane_bits), 63);
+            if (fits && ((32u * (wpos + done_words + 1u) + open_new + 31u) >> 5) < kEncCapWords) {
+                if (FULLT && !__any(lane_bits > 128u))
+                    place_words(cw, buf_bits + P_lane + lane_bits);
+                else
+                    emit_tile<FULLT>(pc, buf_bits + P_lane);
+                if (pk_end) buf[wpos_my] = n_w;  // (after the tile's ORs, in program order: an OR of zero may touch this word)
+            } else {
+                fits = false;
+            }
+            if (pk_end) wave_words[q.wave_base + w0 + pk_wi] = n_w;
+            wpos += done_words;
+            open_bits = open_new;
+            return;
+        }
         const uint32_t P = (runs ? 32u * (wpos + 1u) : 0u) + Pw;  // bit of buf where the tile starts
         if (fits && ((P + tile_bits + 31u) >> 5) < kEncCapWords) {
             if (FULLT && !__any(lane_bits > 128u))
@@ -275,7 +329,7 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
         if (c.i >= nspans) return;
         if (c.rem >= (uint32_t)kTile) process(c, qv, std::true_type{}); else process(c, qv, std::false_type{});
         if (c.rem <= (uint32_t)kTile) {  // the span's last tile
-            if (runs) {
+            if (runs && !PACKED) {
                 const uint32_t n = (Pw + 31u) >> 5;
                 if (lane == 0) {
                     if (fits) buf[wpos] = n;
@@ -416,7 +470,7 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
     const uint64_t pos = s_excl + ((SUPER ? w0 == 0u : first_wg) ? 1ull : 0ull) + words_before;
 
     // a waveform coded once more, tile by tile, straight to its place (its code did not fit the buffer)
-    auto stream_waveform = [&](uint64_t soff, uint32_t len, uint32_t *__restrict__ outp) {
+    auto stream_waveform = [&](uint64_t soff, uint32_t len, uint32_t *__restrict__ outp) -> uint64_t {
         for (int i = lane; i < (int)(kEncCapWords + 8) / 4; i += 64) reinterpret_cast<uint4 *>(row)[i] = make_uint4(0, 0, 0, 0);
         wave_sync();
         const int16_t *x = in + soff;
@@ -451,22 +505,25 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
             wave_sync();
         }
         if ((P & 31u) && lane == 0) outp[P >> 5] = buf[0];
+        return P;
     };
 
     if (runs) {
         const uint32_t words = s_size[wv];
-        if ((uint32_t)lane < nspans) wave_words[q.wave_base + w0 + (uint32_t)lane] = s_n[wv][lane];
+        if (!PACKED && (uint32_t)lane < nspans) wave_words[q.wave_base + w0 + (uint32_t)lane] = s_n[wv][lane];
         if (pos + words > out_cap) return;  // the last workgroup raises kErrCapacity
         if (fits) {
             for (uint32_t i = lane; i < words; i += 64) out[pos + i] = buf[i];
             return;
         }
         uint64_t at = pos;
-        for (uint32_t i = 0; i < nspans; ++i) {
-            const uint32_t n = s_n[wv][i];
+        const uint32_t n_wf = PACKED ? run_wfs : nspans;
+        for (uint32_t i = 0; i < n_wf; ++i) {
+            const uint32_t len_i = (w0 + i + 1u == q.W) ? q.n_samples - (w0 + i) * q.L : q.L;
+            const uint64_t bits = stream_waveform(wf_off + (uint64_t)i * q.L, len_i, out + at + 1u);
+            const uint32_t n = (uint32_t)((bits + 31u) >> 5);
             if (lane == 0) out[at] = n;  // src/deltaRice.c:379
             wave_sync();
-            stream_waveform(wf_off + (uint64_t)i * q.L, span_len(i), out + at + 1u);
             at += 1u + n;
         }
         return;
@@ -594,26 +651,29 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
 // the segment encoder.
 // debug_flags: 4096 never this encoder, 8192 always the segment encoder, 32768 this encoder also where WaveformLength is in
 // k_encode_fused's own range (one waveform per wavefront; the tests compare the two that way).
+static bool pieces_packed(const Geom &G) { return G.uniform ? piece_packable(G.u_wave_len) : G.pc_packed != 0; }
+static bool pieces_super(const Geom &G) { return G.uniform ? G.u_wave_len > kPcMaxLen : G.pc_super != 0; }
+
 bool pieces_batch(const Geom &G) {
     if ((G.n_taps && !G.enc_fast) || (G.dbg & (8192u | 4096u))) return false;  // delta, or a forward filter of up to four taps
     const bool force = (G.dbg & 32768u) != 0;
     if (G.uniform) {
         const uint32_t L = G.u_wave_len;
-        if (L < kPcMinLen) return false;
+        const bool packed = piece_packable(L);
+        if (L < kPcMinLen && !packed) return false;
         if ((uint64_t)G.n_chunks * G.u_n_samples < (uint64_t)kTile) return false;
-        const PieceShape sh = piece_shape(L, G.u_n_waves);
+        const PieceShape sh = piece_shape(L, G.u_n_waves, packed);
         if ((uint64_t)G.u_n_waves * sh.parts > 0x7fffffffull || (uint64_t)sh.wgs * G.n_chunks > 0x7fffffffull) return false;
-        return force || sh.run > 1u || sh.segs > 1u;
+        return force || packed || sh.run > 1u || sh.segs > 1u;
     }
     return G.pc_wg_base != nullptr;  // decided when the plan was made
 }
 
-static bool pieces_super(const Geom &G) { return G.uniform ? G.u_wave_len > kPcMaxLen : G.pc_super != 0; }
-
 uint64_t pieces_workgroups(const Geom &G, const ChunkDesc *host_chunks) {
-    if (G.uniform) return (uint64_t)piece_shape(G.u_wave_len, G.u_n_waves).wgs * G.n_chunks;
+    const bool packed = pieces_packed(G);
+    if (G.uniform) return (uint64_t)piece_shape(G.u_wave_len, G.u_n_waves, packed).wgs * G.n_chunks;
     uint64_t t = 0;
-    for (uint64_t c = 0; c < G.n_chunks; ++c) t += piece_shape(host_chunks[c].wave_len, host_chunks[c].n_waves).wgs;
+    for (uint64_t c = 0; c < G.n_chunks; ++c) t += piece_shape(host_chunks[c].wave_len, host_chunks[c].n_waves, packed).wgs;
     return t;
 }
 
@@ -633,17 +693,18 @@ hipError_t launch_encode_pieces(const Geom &G, const int16_t *d_in, uint64_t in_
     if (e != hipSuccess) return e;
     if (ev) { (void)hipEventRecord(ev[1], s); (void)hipEventRecord(ev[2], s); }
     uint32_t *ticket = reinterpret_cast<uint32_t *>(d_scan + words - 2u);
-    auto go = [&](auto super_tag, auto gen_tag) {
-        constexpr bool SUPER = decltype(super_tag)::value, GEN = decltype(gen_tag)::value;
-        k_encode_pieces<SUPER, GEN><<<(unsigned)total_wgs, 64 * kPcWaves, 0, s>>>(
+    auto go = [&](auto super_tag, auto gen_tag, auto packed_tag) {
+        constexpr bool SUPER = decltype(super_tag)::value, GEN = decltype(gen_tag)::value, PACKED = decltype(packed_tag)::value;
+        k_encode_pieces<SUPER, GEN, PACKED><<<(unsigned)total_wgs, 64 * kPcWaves, 0, s>>>(
             G, d_in, in_samples, d_out, out_cap, d_chunk_word_off, d_wave_words, d_scan, SUPER ? d_scan + G.total_waves : nullptr, ticket,
             (uint32_t)total_wgs, d_status);
     };
-    const bool sup = pieces_super(G), gen = G.n_taps != 0;
-    if (sup && gen) go(std::true_type{}, std::true_type{});
-    else if (sup) go(std::true_type{}, std::false_type{});
-    else if (gen) go(std::false_type{}, std::true_type{});
-    else go(std::false_type{}, std::false_type{});
+    const bool sup = pieces_super(G), gen = G.n_taps != 0, packed = pieces_packed(G);
+    const std::true_type T;
+    const std::false_type F;
+    if (sup) { if (gen) go(T, T, F); else go(T, F, F); }
+    else if (packed) { if (gen) go(F, T, T); else go(F, F, T); }
+    else { if (gen) go(F, T, F); else go(F, F, F); }
     if (ev) (void)hipEventRecord(ev[3], s);
     return hipGetLastError();
 }

@@ -204,6 +204,17 @@ PIECE_CASES = [
     (2, 512 * 20, 512, 0, "zeros"),            # one bit per sample
     (2, 20000 * 2, 20000, 0, "zeros"),
     (3, 2000 * 10, 2000, 15, "uniform"),
+    # packed runs (WaveformLength < 512, a multiple of 8): tiles span waveform boundaries
+    (3, 64 * 300 + 13, 64, 3, "gauss10"),          # eight waveforms per tile; a 13-sample leftover waveform
+    (2, 8 * 2000 + 3, 8, 3, "gauss10"),            # a waveform per lane
+    (2, 16 * 999, 16, 2, "steps"),
+    (2, 128 * 77, 128, 3, "gauss300"),
+    (3, 200 * 101 + 150, 200, 3, "gauss10"),       # 25 lanes per waveform: boundaries wander through the tiles
+    (2, 256 * 40, 256, 4, "gauss10"),
+    (2, 504 * 30 + 500, 504, 3, "gauss10"),
+    (2, 64 * 200, 64, 3, "uniform"),               # incompressible: the run outgrows the buffer, waveforms coded again one by one
+    (2, 128 * 100, 128, 0, "zeros"),               # one bit per sample
+    (1, 24 * 700, 24, 15, "uniform"),
     # waveforms over several workgroups (WaveformLength above 65 536): parts of eight segments
     (2, 70000 * 3 + 5000, 70000, 3, "gauss10"),    # two parts; a short leftover waveform
     (3, 81920 * 2, 81920, 3, "gauss10"),           # the reference's nEDM shape (docs/Performance.md:27)
@@ -276,7 +287,9 @@ def test_pieces_encoder_ragged_long_waveforms(ctx, O):
     mixes them with shorter ones stays with the segment encoder.  Both must give the reference's bytes."""
     rng = np.random.default_rng(78)
     for Ls, Ns in (([70000, 0, 100000, 131072], [70000 * 2 + 9, 250000, 100000 * 3, 131072 + 131071]),
-                   ([70000, 512, 100000], [70000 * 2, 512 * 9, 100000])):
+                   ([70000, 512, 100000], [70000 * 2, 512 * 9, 100000]),
+                   ([64, 256, 128, 8], [64 * 90 + 5, 256 * 33, 128 * 50, 8 * 700]),     # every chunk packable: packed runs
+                   ([64, 7000, 128], [64 * 90, 7000 * 3, 128 * 50])):                  # packable chunks beside others: plain runs
         xs = [make_data(rng, "uniform" if c == 1 else "gauss10", n) for c, n in enumerate(Ns)]
         x = np.concatenate(xs)
         plan = ctx.plan(Ns, Ls, 8)
@@ -501,7 +514,7 @@ def test_general_filters_through_the_pieces_encoder(ctx, O):
     boundaries, src/deltaRice.c:64-74); incompressible data takes the coded-again paths."""
     rng = np.random.default_rng(78)
     for taps in [(1, -1, 1, -1), (-1, 3, -3, 1), (2, -1), (1, -2, 1)]:
-        for n_chunks, N, L, kind in [(2, 512 * 21 + 100, 512, "gauss10"), (2, 700 * 9, 700, "gauss300"), (1, 16384 * 3 + 999, 16384, "gauss10"),
+        for n_chunks, N, L, kind in [(2, 64 * 150 + 9, 64, "gauss10"), (1, 200 * 60, 200, "gauss300"), (2, 512 * 21 + 100, 512, "gauss10"), (2, 700 * 9, 700, "gauss300"), (1, 16384 * 3 + 999, 16384, "gauss10"),
                                      (2, 70000 * 2 + 30000, 70000, "gauss10"), (1, 150000, 0, "steps"), (1, 2048 * 6, 2048, "uniform"),
                                      (1, 20000 * 2, 20000, "uniform"), (1, 140000, 140000, "uniform")]:
             x = make_data(rng, kind, n_chunks * N)

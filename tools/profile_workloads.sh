@@ -10,11 +10,17 @@ cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
+# the HIP-event timings of every workload first: the profiler passes (the --pmc ones in particular) may leave the device in
+# another state for whatever runs after them in the same session
 for name in "$@"; do
   W=$O/work_$name
   rm -rf $W && mkdir -p $W
+  [ -n "$SKIP_PLAIN" ] && continue
   timeout -k 10 300 python3 tools/workload.py $name > $O/${TAG}_${name}.json 2> $W/plain.err
   cat $O/${TAG}_${name}.json
+done
+for name in "$@"; do
+  W=$O/work_$name
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $W/stats -o s --output-format csv -- python3 tools/workload.py $name --steps 3 > $W/stats.log 2>&1
   python3 profiles/trim_stats.py $W/stats/s_kernel_stats.csv $O/${TAG}_${name}_kernel_stats.csv
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_EA0_RDREQ_sum -d $W/pmc_rd -o p --output-format csv -- python3 tools/workload.py $name --steps 2 > $W/pmc_rd.log 2>&1

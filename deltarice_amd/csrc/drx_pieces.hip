@@ -13,6 +13,11 @@
 //            of every segment, segment s is copied out shifted to its bit position inside the waveform's stream, the word
 //            it shares with segment s + 1 completed from that wavefront's buffer (LDS, no global atomics, no zeroing);
 //   else     one waveform, as k_encode_fused.
+// PACKED (every WaveformLength below 512 and a multiple of 8): a 512-sample tile per waveform would be mostly empty lanes, so
+// a run's samples form ONE sequence of full tiles that span waveform boundaries (a lane's 8 samples belong to one
+// waveform); segmented scans give every lane its bit inside its waveform and every waveform its header word.
+// GEN: a forward filter of up to four taps (src/deltaRice.c:64-74) instead of the delta; its three samples of history cross
+// tile, segment and part boundaries and stop at waveform boundaries.
 // SUPER (every WaveformLength above 65 536, among them the reference's default of one waveform per chunk): a waveform is
 // cut into PARTS of eight segments, a workgroup each.  The bits in front of a part come from a second look-back over the
 // parts of its waveform, the waveform's place from the first one, which then has one entry per WAVEFORM, published by

@@ -157,7 +157,8 @@ __host__ __device__ inline PieceShape piece_shape(uint32_t L, uint32_t W, bool p
         s.pieces = W * s.segs;
         s.wgs = (s.pieces + kPcWaves - 1u) / kPcWaves;
     } else {
-        // a waveform over several workgroups ("parts"): kPcWaves segments each, as even as whole tiles allow
+        // a waveform over several workgroups ("parts"): kPcWaves segments each, as even as whole tiles allow (full 8192-sample
+        // segments with a short last part instead were measured slower: nEDM 0.90 against 0.77 ms)
         s.run = 1u;
         s.segs = kPcWaves;
         s.parts = (uint32_t)(((uint64_t)L + kPcMaxLen - 1u) / kPcMaxLen);

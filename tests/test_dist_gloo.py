@@ -73,6 +73,46 @@ def test_sharded_encode_is_byte_identical(tmp_path, world, n_chunks):
         assert np.array_equal(p["goff"], ref_off[f:f + c + 1].astype(np.int64)), "global chunk offsets differ"
 
 
+def _scatter_worker(rank, world, port, n_chunks, chunk_samples, opts, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        x = np.random.default_rng(5).normal(0, 10, n_chunks * chunk_samples).astype(np.int16)
+        src = world - 1  # (not rank 0: the helpers take the root as an argument)
+        mine = drdist.scatter_chunks(torch.from_numpy(x) if rank == src else None, n_chunks, chunk_samples, device="cpu", src=src)
+        first, count = drdist.shard_range(n_chunks, world, rank)
+        assert np.array_equal(mine.numpy(), x[first * chunk_samples:(first + count) * chunk_samples]), "scatter: wrong share"
+        if count:
+            words, _ = O.encode_batch(mine.numpy(), chunk_samples, opts)
+        else:
+            words = np.zeros(0, np.uint32)
+        buf = torch.zeros(words.size + 17, dtype=torch.int32)  # (an output buffer is larger than what was encoded)
+        buf[:words.size] = torch.from_numpy(words.view(np.int32))
+        out, offs = drdist.gather_encoded(buf, words.size, dst=0)
+        assert int(offs[rank + 1] - offs[rank]) == words.size
+        if rank == 0:
+            np.save(os.path.join(outdir, "gathered.npy"), out.numpy().view(np.uint32))
+        else:
+            assert out is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_chunks", [(2, 5), (3, 7), (3, 2)])
+def test_root_resident_batch_scatter_and_gather(tmp_path, world, n_chunks):
+    """SURVEY 8e's optional data movement: the raw batch starts on one rank, the encoded stream ends on one rank; what arrives
+    is the stream a single rank would have produced."""
+    from oracle import oracle as O
+    chunk_samples, opts = 3 * 1000, (8, 1000)
+    mp.spawn(_scatter_worker, args=(world, _free_port(), n_chunks, chunk_samples, opts, str(tmp_path)), nprocs=world, join=True)
+    x = np.random.default_rng(5).normal(0, 10, n_chunks * chunk_samples).astype(np.int16)
+    ref_words, _ = O.encode_batch(x, chunk_samples, opts)
+    assert np.array_equal(np.load(tmp_path / "gathered.npy"), ref_words)
+
+
 def test_bench_gpus_n_without_devices_fails_loudly():
     """`python bench.py --gpus N` is the driver's multi-GPU command: with fewer than N devices it must exit
     non-zero and print no JSON line (it used to run one rank and report n_gpus: 1)."""

@@ -367,13 +367,18 @@ drx_status drx_plan_create(drx_ctx *ctx, uint64_t n_chunks, const uint32_t *chun
             for (uint64_t c = 0; c < n_chunks; ++c) by_len[c] = (uint32_t)c;
             std::stable_sort(by_len.begin(), by_len.end(), [&](uint32_t a, uint32_t b) { return desc[a].wave_len > desc[b].wave_len; });
             std::vector<uint2> order;
+            uint64_t n_long_groups = 0;
             for (uint32_t c : by_len)
-                for (uint32_t j = 0; j < (desc[c].n_waves + 63u) / 64u; ++j) order.push_back(make_uint2(c, j));
+                for (uint32_t j = 0; j < (desc[c].n_waves + 63u) / 64u; ++j) {
+                    order.push_back(make_uint2(c, j));
+                    if (desc[c].wave_len > kWalkShortLenHost) ++n_long_groups;
+                }
             if (order.size() <= 0x7fffffffull) {
                 if (e == hipSuccess) e = hipMalloc((void **)&p->d_rag_order, order.size() * sizeof(uint2));
                 if (e == hipSuccess) e = hipMemcpy(p->d_rag_order, order.data(), order.size() * sizeof(uint2), hipMemcpyHostToDevice);
                 p->G.rag_order = p->d_rag_order;
                 p->G.rag_groups = (uint32_t)order.size();
+                p->G.rag_groups_long = (uint32_t)n_long_groups;
             }
         }
         // parallel header walks for small ragged batches: every long-waveform chunk within the chunk-wide walk's

@@ -42,6 +42,7 @@ struct Geom {
                    //   256 never take the long-waveform paths   512 long waveforms: one workgroup per waveform only
                    //  2048 never take the parallel header walks of small batches   8192 always the segment encoder
                    //  4096 never the pieces encoder   32768 the pieces encoder wherever its geometry allows
+                   //  131072 ragged batches: one decode launch behind both header walks instead of one behind each
                    // Ablation switches INSIDE the kernels, compiled only with -DDRX_ABLATION (results invalid):
                    //   decode:   1 skip the output stores   2 skip the stream loads
                    //             4 request pieces without counting on the round's minimum consumption   16384 long: no stores
@@ -63,6 +64,7 @@ struct Geom {
     // wavefront, longest WaveformLength first; rag_groups entries
     const uint2 *rag_order;
     uint32_t rag_groups;
+    uint32_t rag_groups_long;  // ... of which the first ones belong to chunks of WaveformLength > 2048 (the chunk-wide walk's)
     // ragged batches the pieces encoder takes (drx_pieces.hip): first workgroup of every chunk, n_chunks + 1 entries
     const uint32_t *pc_wg_base;
     uint32_t pc_super;  // ... and every chunk's WaveformLength is above kPcMaxLen (waveforms over several workgroups)

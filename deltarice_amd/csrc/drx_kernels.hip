@@ -2468,6 +2468,16 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
         else
             k_decode_lanes<64, 16, 64, 16, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out);
     } else {
+        // the lane-per-waveform launch outside the fused form (tables in wave_off / wave_words): `nb` wavefronts of view Gv
+        auto launch_lanes = [&](const Geom &Gv, unsigned nb, int im, hipStream_t st_) {
+            if (im == 7 && gen)
+                k_decode_lanes<64, 16, 64, 16, false, true, true><<<nb, 64, 0, st_>>>(Gv, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out);
+            else if (im == 7)
+                k_decode_lanes<64, 16, 64, 16, false, true><<<nb, 64, 0, st_>>>(Gv, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out);
+            else
+                k_decode_lanes<64, 16, 64, 16, false><<<nb, 64, 0, st_>>>(Gv, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out);
+        };
+        bool lanes_done = false;
         // chunks of short waveforms: stream the chunk through LDS; long waveforms: one dependent load per hop
         if (tables_ready) {
         } else if (par_walk || bw_walk || rag_par) {
@@ -2498,6 +2508,17 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                 k_walk_scalar_only<<<blocks_for(G.n_chunks, kWalkChains), 64, 0, spw>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off,
                                                                                         d_wave_words, d_status, pw_fail);
             }
+            // ... and so does the decoding of the long-waveform chunks, whose tables are complete long before the block walk is
+            // through: their wavefronts (the first rag_groups_long of the longest-first order) are launched behind the
+            // chunk-wide walk on the side stream, the rest here behind the block walk
+            const int im_split = (impl == 0) ? 0 : ((impl == 5 || impl == 1) ? 1 : 7);
+            const bool split = forked && G.rag_order && im_split != 0 && G.rag_groups_long && G.rag_groups_long < G.rag_groups &&
+                               !(G.dbg & 131072u);
+            if (split) {
+                Geom Gl = G;
+                Gl.rag_groups = G.rag_groups_long;
+                launch_lanes(Gl, Gl.rag_groups, im_split, spw);
+            }
             if (forked && (e = hipEventRecord(side->join, side->s)) != hipSuccess) return e;
             if (use_bw) {
                 // block size: the smallest that exceeds every listed chunk's max_words; wavefronts: what the LDS lets the chip hold
@@ -2526,6 +2547,14 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                 else run_bw(std::integral_constant<uint32_t, 4096>{}, 7u);
                 k_walk_block_only<<<(unsigned)G.n_chunks, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_status, bw_fail);
             }
+            if (split) {
+                mark(ev, 1, s);  // (the block walk's end; the other stream is decoding already)
+                Geom Gs = G;
+                Gs.rag_order = G.rag_order + G.rag_groups_long;
+                Gs.rag_groups = G.rag_groups - G.rag_groups_long;
+                launch_lanes(Gs, Gs.rag_groups, im_split, s);
+                lanes_done = true;
+            }
             if (forked && (e = hipStreamWaitEvent(s, side->join, 0)) != hipSuccess) return e;
             if (impl == 5) impl = 1;
             if (impl == 8) impl = 7;
@@ -2541,6 +2570,11 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                                                                  d_wave_off, d_wave_words, d_status);
             if (G.n_long) k_walk_list<<<blocks_for(G.n_long, 64), 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, G.walk_long,
                                                                              G.n_long, d_wave_off, d_wave_words, d_status);
+        }
+        if (lanes_done) {
+            mark(ev, 2, s);
+            mark(ev, 3, s);
+            return hipGetLastError();
         }
         mark(ev, 1, s);
         const unsigned nb_plain = blocks_for(G.total_waves, 64);
@@ -2566,12 +2600,8 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
         const unsigned nb = (!G.uniform && G.rag_order) ? G.rag_groups : nb_plain;  // (groups per chunk round up)
         if (impl == 0)
             k_decode_simple<<<nb_plain, 64, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_status, d_out);
-        else if (impl == 7 && gen)
-            k_decode_lanes<64, 16, 64, 16, false, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out);
-        else if (impl == 7)
-            k_decode_lanes<64, 16, 64, 16, false, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out);
         else
-            k_decode_lanes<64, 16, 64, 16, false><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out);
+            launch_lanes(G, nb, impl, s);
     }
     mark(ev, 2, s);
     mark(ev, 3, s);

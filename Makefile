@@ -27,7 +27,7 @@ PY_INC    := $(shell $(PYTHON) -c "import sysconfig; print(sysconfig.get_paths()
 PYEXT     := deltaRice/h5$(PY_SUFFIX)
 PLUGIN_DIR ?= /usr/local/hdf5/lib/plugin
 
-.PHONY: all hip plugin h5io pyext install-plugin oracle clean
+.PHONY: all hip plugin h5io pyext install-plugin oracle asan check-asm clean
 all: hip plugin h5io pyext
 
 hip: $(HIP_LIB)
@@ -35,7 +35,12 @@ hip: $(HIP_LIB)
 $(CSRC)/%.o: $(CSRC)/%.hip $(HIP_HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(HIP_LIB): $(HIP_OBJS)
+	$(PYTHON) tools/check_asm_hazards.py $(HIP_OBJS)
 	$(HIPCC) $(HIPFLAGS) -shared $(HIP_OBJS) -o $@
+# the hazards a hand-written asm statement can hide from the compiler (VALU-written SGPR base within five wait states of a
+# vector-memory instruction; a returning atomic's destination touched before its s_waitcnt), on the gfx950 disassembly
+check-asm: $(HIP_OBJS)
+	$(PYTHON) tools/check_asm_hazards.py $(HIP_OBJS)
 
 plugin: $(PLUGIN)
 $(PLUGIN): $(CSRC)/h5z_deltarice.c include/deltarice_h5filter.h include/deltarice_hip.h $(HIP_LIB)
@@ -52,7 +57,17 @@ $(H5IO): $(CSRC)/h5_direct.c include/deltarice_h5io.h include/deltarice_hip.h $(
 
 # deltaRice/h5.pyx -> deltaRice/h5.cpython-*.so, linked against the plugin library (whose callback runs the HIP codec).
 # h5py is needed to IMPORT the module, not to build it.
+# Best effort inside `all`: a box without cython or the Python headers still builds the codec library and the plugin
+# (`make pyext-strict` fails loudly instead).
+HAVE_PYEXT_TOOLS := $(shell command -v $(CYTHON) >/dev/null 2>&1 && [ -f "$(PY_INC)/Python.h" ] && echo yes)
+ifeq ($(HAVE_PYEXT_TOOLS),yes)
 pyext: $(PYEXT)
+else
+pyext:
+	@echo "pyext: skipped ($(CYTHON) or $(PY_INC)/Python.h not found); deltaRice.h5 needs it, the codec and the HDF5 plugin do not"
+endif
+.PHONY: pyext-strict
+pyext-strict: $(PYEXT)
 $(PYEXT): deltaRice/h5.pyx include/deltarice_h5filter.h $(PLUGIN)
 	@mkdir -p build/pyext
 	$(CYTHON) -3 -o build/pyext/h5.c deltaRice/h5.pyx
@@ -69,6 +84,9 @@ install-plugin: $(PLUGIN) $(HIP_LIB)
 
 oracle:
 	$(MAKE) -C oracle all
+# CPU-side sanitizer builds of the restatement, the plugin's C source and the HDF5 test driver (tests/test_sanitizers.py)
+asan: $(HIP_LIB)
+	$(MAKE) -C oracle asan
 
 clean:
 	rm -f $(HIP_LIB) $(HIP_OBJS) $(PLUGIN) $(H5IO) $(PYEXT)

@@ -60,7 +60,53 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; "
                     "gloo only to rehearse the multi-rank flow on one GPU)")
     ap.add_argument("--debug-flags", type=int, default=0, help="kernel ablation switches (profiling only; results invalid)")
+    ap.add_argument("--collect-traffic", dest="collect_traffic", action="store_true", default=None,
+                    help="measure roofline.traffic in THIS run: two rocprofv3 --pmc passes of this command as child processes "
+                         "before this process touches the GPU (default: on for --gpus 1 with the default workload)")
+    ap.add_argument("--no-collect", dest="collect_traffic", action="store_false", help="do not run the PMC passes")
     return ap.parse_args()
+
+
+def _traffic_tools():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_traffic_json", os.path.join(ROOT, "profiles", "make_traffic_json.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def collect_traffic(a):
+    """HBM bytes per launch of the headline kernels, measured by this run: the two PMC passes MI355X_MICROARCH.md
+    prescribes (FETCH_SIZE and WRITE_SIZE cannot share a pass), each a fresh child process with the program directly
+    behind `rocprofv3 ... --` (this process has not touched the GPU yet and never execs).  Returns (kernels, source) or
+    (None, why)."""
+    import shutil
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None, "rocprofv3 not found"
+    tools = _traffic_tools()
+    fwd = ["--waves", str(a.waves), "--wave-len", str(a.wave_len), "--chunk-waves", str(a.chunk_waves), "--m", str(a.m),
+           "--dist", a.dist, "--decode-impl", str(a.decode_impl), "--seed", str(a.seed)]
+    passes = (("rd", ["FETCH_SIZE", "TCC_EA0_RDREQ_sum"]), ("wr", ["WRITE_SIZE", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"]))
+    csvs = []
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for tag, counters in passes:
+            out = os.path.join(td, tag)
+            cmd = [exe, "--kernel-trace", "--pmc"] + counters + ["-d", out, "-o", "p", "--output-format", "csv", "--",
+                   sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0",
+                   "--no-collect"] + fwd
+            try:
+                r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=240)
+            except subprocess.TimeoutExpired:
+                return None, f"PMC pass {tag} timed out"
+            found = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not found:
+                return None, f"PMC pass {tag} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}"
+            csvs += found
+        kernels = tools.summarise(csvs)
+    return kernels, ("this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 3 --warmup 1 --cpu-seconds 0` as child "
+                     "processes (FETCH_SIZE x 2 per MI355X_MICROARCH.md), mean per launch")
 
 
 def synth(device, n_waves, L, kind, seed):
@@ -191,6 +237,12 @@ def main():
             dist.init_process_group(a.backend)
         if dist.get_world_size() != a.gpus:
             raise SystemExit(f"bench.py: the process group has {dist.get_world_size()} ranks, --gpus says {a.gpus}")
+    # in-run HBM traffic (child processes; nothing in this process has touched the GPU yet)
+    traffic_kernels = traffic_note = None
+    default_workload = (a.waves, a.wave_len, a.chunk_waves, a.m, a.dist) == (1_000_000, 7000, 2000, 8, "gauss")
+    want = a.collect_traffic if a.collect_traffic is not None else (world == 1 and default_workload and not a.debug_flags)
+    if want and world == 1:
+        traffic_kernels, traffic_note = collect_traffic(a)
     import deltarice_amd as dr
     from deltarice_amd import dist as drdist
 
@@ -265,18 +317,27 @@ def main():
     achieved = algo_bytes / (dec_kernel_ms * 1e-3) / 1e9
     pack_ms = float(np.mean(np.array(coll["enc"])[:, 2]))
 
-    # HBM bytes per launch: NOT measured by this run (PMC counters cannot be collected from inside the timed
-    # process) but read from the committed rocprofv3 --pmc passes of this same command and workload
-    # (FETCH_SIZE x 2 + WRITE_SIZE, profiles/make_traffic_json.py); `traffic_source` says so in the JSON line
+    # HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, profiles/make_traffic_json.py): measured by THIS run's own PMC
+    # passes (collect_traffic(), before the GPU was touched) -- or, where rocprofv3 is missing or a pass failed, read from the
+    # newest committed passes of the same command, flagged stale when the kernel sources have changed since
     traffic = traffic_enc = traffic_source = None
-    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
-    if tfiles and n_waves == 1_000_000 and L == 7000 and a.m == 8 and a.dist == "gauss":
-        with open(tfiles[-1]) as f:
-            tk = json.load(f)["kernels"]
-        traffic = tk.get("k_decode_lanes", {}).get("hbm_bytes")
-        traffic_enc = tk.get("k_encode_fused", {}).get("hbm_bytes")
-        traffic_source = (f"profiles/{os.path.basename(tfiles[-1])}: rocprofv3 --pmc passes of this command on an earlier "
-                          "run, not collected by this run")
+    if traffic_kernels is not None:
+        traffic = traffic_kernels.get("k_decode_lanes", {}).get("hbm_bytes")
+        traffic_enc = traffic_kernels.get("k_encode_fused", {}).get("hbm_bytes")
+        traffic_source = traffic_note
+    else:
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+        if tfiles and n_waves == 1_000_000 and L == 7000 and a.m == 8 and a.dist == "gauss":
+            with open(tfiles[-1]) as f:
+                tj = json.load(f)
+            stale = tj.get("kernel_sources_sha16") != _traffic_tools().kernel_sources_sha()
+            if not stale:
+                traffic = tj["kernels"].get("k_decode_lanes", {}).get("hbm_bytes")
+                traffic_enc = tj["kernels"].get("k_encode_fused", {}).get("hbm_bytes")
+            traffic_source = (f"profiles/{os.path.basename(tfiles[-1])} (commit {tj.get('git_head')}): rocprofv3 --pmc passes of this "
+                              "command on an earlier run, NOT collected by this run"
+                              + ("; dropped: the kernel sources have changed since" if stale else "")
+                              + (f"; in-run collection: {traffic_note}" if traffic_note else ""))
 
     # every rank reports its device and encoded size: rank 0 prints what it SAW, not what it was told
     rank_info = [[rank, local, total_words * 4]]

@@ -222,6 +222,7 @@ drx_status drx_ctx_synchronize(drx_ctx *c) {
 
 const char *drx_ctx_last_error(const drx_ctx *c) { return c ? c->last_error.c_str() : ""; }
 void *drx_ctx_stream(const drx_ctx *c) { return c ? (void *)c->stream : nullptr; }
+int drx_ctx_device(const drx_ctx *c) { return c ? c->device : -1; }
 
 drx_status drx_ctx_set_option(drx_ctx *c, const char *key, int64_t value) {
     if (!c || !key) return DRX_ERR_ARG;
@@ -271,8 +272,7 @@ static void plan_free(drx_plan *p) {
     delete p;
 }
 
-static drx_status plan_alloc(drx_ctx *ctx, drx_plan *p) {
-    DRX_ON_DEVICE(ctx);
+static drx_status plan_alloc(drx_ctx *ctx, drx_plan *p) {  // (callers hold the device guard)
     const uint64_t W = p->G.total_waves ? p->G.total_waves : 1;
     DRX_HIP(ctx, hipMalloc((void **)&p->d_wave_words, W * sizeof(uint32_t)));
     DRX_HIP(ctx, hipMalloc((void **)&p->d_wave_rel, W * sizeof(uint32_t)));
@@ -313,6 +313,7 @@ drx_status drx_plan_create(drx_ctx *ctx, uint64_t n_chunks, const uint32_t *chun
     *out = nullptr;
     if (rice_k > 15) return fail(ctx, DRX_ERR_ARG, "rice_k %u out of range 0..15", rice_k);
     if (n_chunks > 0xffffffffull) return fail(ctx, DRX_ERR_ARG, "too many chunks");
+    DRX_ON_DEVICE(ctx);  // every allocation and table upload below, plan_alloc_scratch() included, lands on the context's device
     std::vector<ChunkDesc> desc(n_chunks);
     uint64_t soff = 0, wbase = 0, maxw = 0;
     bool uniform = true;
@@ -460,6 +461,7 @@ drx_status drx_plan_create_uniform(drx_ctx *ctx, uint64_t n_chunks, uint32_t chu
     if (n_chunks > 0xffffffffull) return fail(ctx, DRX_ERR_ARG, "too many chunks");
     const uint32_t L = wave_len ? wave_len : chunk_samples;
     if (L > 0x7fffffffu) return fail(ctx, DRX_ERR_ARG, "bad waveform length");
+    DRX_ON_DEVICE(ctx);  // (as in drx_plan_create)
     const uint32_t W = (uint32_t)(((uint64_t)chunk_samples + L - 1) / L);
     drx_plan *p = new (std::nothrow) drx_plan;
     if (!p) return DRX_ERR_NOMEM;

@@ -316,13 +316,14 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
     if (cur.blk_lo < cur.blk_hi) fetch_image(cur, cur.blk_lo, img);
     for (;;) {
         // the next ticket, drawn a run ahead.  Inline asm: a returning atomic the compiler sees inside `if (tid == 0)` is
-        // waited for at the end of that branch; this one is waited for where its value is used.  (s_nop 4: the compiler pads
-        // nothing inside an asm statement, and the base it hands over may have been restored from a spill by the
-        // instruction in front -- an SGPR written by VALU needs five wait states before a memory instruction reads it as
-        // its base.  Found the hard way: an experimental two-pass form of this kernel, with other register pressure,
-        // faulted on address 0 until the s_nop was there.)
+        // waited for at the end of that branch; this one is waited for where its value is used.  The address travels in a
+        // VGPR pair (`off` form): the hardware interlocks VGPR operands, whereas an SGPR base restored from a spill by
+        // v_readlane in the instruction in front needs five wait states that nothing pads inside an asm statement (round 2:
+        // an experimental form of this kernel faulted on address 0 that way).  tools/check_asm_hazards.py, run by `make hip`
+        // on the gfx950 disassembly, checks both that rule and that nothing touches next_ticket before the s_waitcnt below.
         uint32_t next_ticket = 0;
-        if (tid == 0) asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=v"(next_ticket) : "v"(0u), "v"(1u), "s"(ticket) : "memory");
+        if (tid == 0)
+            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(next_ticket) : "v"((uint64_t)(uintptr_t)ticket), "v"(1u) : "memory");
         BLK_STAMP(0);  // ticket
         const uint64_t g = cur.g, pay_lo = cur.pay_lo;
         const uint32_t n = cur.n, blk_lo = cur.blk_lo, blk_hi = cur.blk_hi;

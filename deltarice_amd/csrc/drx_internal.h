@@ -99,7 +99,10 @@ hipError_t launch_encode_long(const Geom &G, const int16_t *d_in, uint32_t *d_ou
                               uint64_t *d_chunk_words, uint32_t *d_seg_bits, uint64_t *d_seg_pos, DevStatus *d_status,
                               hipEvent_t *ev, hipStream_t s);
 
-// a second stream of the context, for kernels of one call that do not depend on each other (fork / join through events)
+// a second stream of the context, for kernels of one call that do not depend on each other (fork / join through events).
+// One per CONTEXT, shared by all its plans: it relies on the rule of include/deltarice_hip.h that a context and its plans are
+// driven by one thread at a time (a second thread decoding another plan of the same context would re-record fork / join
+// in the middle of this call).  Every path out of launch_decode() after the fork joins, or synchronises the side stream.
 struct SideStream {
     hipStream_t s;
     hipEvent_t fork, join;

@@ -1837,7 +1837,11 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
                                                      DevStatus *st, int16_t *__restrict__ out) {
     static_assert(RW >= 2 * LW && (RW == 32 || RW == 64 || RW == 128) && (LW == 8 || LW == 16 || LW == 32), "ring");
     constexpr int LOG_RW = RW == 32 ? 5 : (RW == 64 ? 6 : 7);
-    constexpr int OSW = T / 2 + 4;  // output row stride in words (16-byte aligned rows)
+#ifndef DRX_DEC_OPAD
+#define DRX_DEC_OPAD 4
+#endif
+    constexpr int OSW = T / 2 + DRX_DEC_OPAD;  // output row stride in words (16- or 8-byte aligned rows)
+    static_assert(OSW % 2 == 0, "rows are read in 8- or 16-byte pieces");
     constexpr int PPS = T / 8;      // 16-byte pieces per stream per round
     constexpr int SPI = 64 / PPS;   // streams per write-out iteration
     constexpr int NV = LW / 4;      // 16-byte loads per piece
@@ -1848,7 +1852,14 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
     // three consecutive words: rows r + 1, r, r - 1)
     __shared__ uint32_t ring_all[(RW + 2) * 64];
     uint32_t *const ring = ring_all + 64;
-    __shared__ __attribute__((aligned(16))) uint32_t obuf[64 * OSW];  // doubles as the start-up tables
+#ifdef DRX_DEC_NOOBUF  // (ablation builds: no transposition buffer, a lane's sample stores go to four words, no write-out)
+    constexpr int OBW = 256;
+    constexpr bool kNoObuf = true;
+#else
+    constexpr int OBW = 64 * OSW;
+    constexpr bool kNoObuf = false;
+#endif
+    __shared__ __attribute__((aligned(16))) uint32_t obuf[OBW];  // doubles as the start-up tables
     uint64_t *tab_off = reinterpret_cast<uint64_t *>(obuf);  // [64] sample offset of step 0 of round 0
     uint32_t *tab_lo = obuf + 128, *tab_hi = obuf + 192;      // [64] each
     static_assert(64 * OSW >= 256, "tables fit in obuf");
@@ -1984,7 +1995,23 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
     const bool in_vec_ok = ((uintptr_t)in & 15u) == 0;
     uint32_t *myring = ring + lane;
     typedef uint16_t __attribute__((may_alias)) u16a;
+#ifdef DRX_DEC_NOOBUF
+    u16a *myout = reinterpret_cast<u16a *>(obuf + lane * 4);
+#define DRX_OIDX(x) ((x) & 6)
+#else
     u16a *myout = reinterpret_cast<u16a *>(obuf + lane * OSW);
+#define DRX_OIDX(x) (x)
+#endif
+    // 16 bytes of a stream's row: one ds_read_b128 where the rows are 16-byte aligned, else two ds_read_b64
+    auto orow16 = [&](int st, int p) __attribute__((always_inline)) -> uint4 {
+        if constexpr (OSW % 4 == 0) {
+            return *reinterpret_cast<const uint4 *>(obuf + st * OSW + 4 * p);
+        } else {
+            const uint2 a = *reinterpret_cast<const uint2 *>(obuf + st * OSW + 4 * p);
+            const uint2 b = *reinterpret_cast<const uint2 *>(obuf + st * OSW + 4 * p + 2);
+            return make_uint4(a.x, a.y, b.x, b.y);
+        }
+    };
 
     auto load_piece = [&](uint4 (&v)[NV], uint32_t ahead = 0) {
         const uint64_t a = A + flw + ahead;
@@ -2112,7 +2139,7 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
                 const uint32_t a1 = (uint32_t)acc;
                 advance((int32_t)(z2 >> 1) ^ -(int32_t)(z2 & 1u));
                 // low halves of the two running sums in one v_perm_b32
-                *reinterpret_cast<uint32_t *>(myout + tg + u) = __builtin_amdgcn_perm((uint32_t)acc, a1, 0x05040100u);
+                *reinterpret_cast<uint32_t *>(myout + DRX_OIDX(tg + u)) = __builtin_amdgcn_perm((uint32_t)acc, a1, 0x05040100u);
             }
             return;
         }
@@ -2142,17 +2169,17 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
                 Q -= used;
             }
             if constexpr (EDGE) Q_end = (tcur + (uint32_t)u + 1u == hi_step) ? Q : Q_end;
-            myout[tg + u] = (uint16_t)acc;
+            myout[DRX_OIDX(tg + u)] = (uint16_t)acc;
         }
     };
 
     auto write_out = [&](uint32_t t0) __attribute__((always_inline)) {
-        if (kAblate && (G.dbg & 1u)) return;
+        if (kNoObuf || (kAblate && (G.dbg & 1u))) return;
         if (t0 >= lo_max && t0 + T <= hi_min) {  // interior round: whole aligned lines only
 #pragma unroll
             for (int i = 0; i < PPS; ++i) {
                 const int st = i * SPI + lane / PPS, p = lane % PPS;
-                const uint4 v = *reinterpret_cast<const uint4 *>(obuf + st * OSW + 4 * p);
+                const uint4 v = orow16(st, p);
                 *(g_uint4 *)(outg + wo_off[i] + t0) = (u32x4v){v.x, v.y, v.z, v.w};
             }
         } else {
@@ -2161,7 +2188,7 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
                 const int st = i * SPI + lane / PPS, p = lane % PPS;
                 const uint32_t tpos = t0 + 8u * (uint32_t)p;  // step index of the piece's first sample
                 if (tpos + 8u > wo_lo[i] && tpos < wo_hi[i]) {
-                    const uint4 v = *reinterpret_cast<const uint4 *>(obuf + st * OSW + 4 * p);
+                    const uint4 v = orow16(st, p);
                     g_i16 *dst = outg + wo_off[i] + t0;
                     if (tpos >= wo_lo[i] && tpos + 8u <= wo_hi[i]) {
                         *(g_uint4 *)dst = (u32x4v){v.x, v.y, v.z, v.w};
@@ -2256,11 +2283,11 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
             if (pneed0) load_piece(pv0);
             if (pneed1) load_piece(pv1, (uint32_t)LW);
         }
-        if (!(kAblate && (G.dbg & 1u))) {
+        if (!(kNoObuf || (kAblate && (G.dbg & 1u)))) {
 #pragma unroll
             for (int i = 0; i < PPS; ++i) {  // whole aligned lines only
                 const int st = i * SPI + lane / PPS, p = lane % PPS;
-                const uint4 v = *reinterpret_cast<const uint4 *>(obuf + st * OSW + 4 * p);
+                const uint4 v = orow16(st, p);
                 *(g_uint4 *)(outg + wo_off[i] + t0) = (u32x4v){v.x, v.y, v.z, v.w};
             }
         }
@@ -2417,11 +2444,26 @@ hipError_t launch_encode_long(const Geom &G, const int16_t *d_in, uint32_t *d_ou
     return hipGetLastError();
 }
 
+// Ablation builds only: DRX_DEC_LDS_PAD = bytes of dynamic LDS added to every k_decode_lanes launch (occupancy A/B at an
+// unchanged instruction stream: 26 KB + pad per wavefront decides how many of them a CU holds).
+static unsigned dec_lds_pad() {
+#ifdef DRX_ABLATION
+    static const unsigned pad = [] { const char *e = getenv("DRX_DEC_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
+    return pad;
+#else
+    return 0u;
+#endif
+}
+
+#ifndef DRX_DEC_T
+#define DRX_DEC_T 64
+#endif
 hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                          const uint64_t *d_chunk_word_off, int16_t *d_out, uint64_t *d_wave_off,
                          uint32_t *d_wave_words, uint64_t *d_granules, DevStatus *d_status, int impl,
                          void *d_pw, void *d_blk, const SideStream *side, hipEvent_t *ev, hipStream_t s) {
     if (G.total_waves == 0) return hipSuccess;
+    const unsigned lpad = dec_lds_pad();
     mark(ev, 0, s);
     // impl >= 100: wave_off / wave_words are already filled in (the one-chunk host path walks the header
     // chain on the CPU while the chunk is in flight to the device): decode with variant impl - 100, no walk
@@ -2462,20 +2504,20 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
         }
         const unsigned nb = n_walk + (unsigned)(G.n_chunks * groups);
         if (impl == 8 && gen)
-            k_decode_lanes<64, 16, 64, 16, true, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out);
+            k_decode_lanes<64, 16, DRX_DEC_T, 16, true, true, true><<<nb, 64, lpad, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out);
         else if (impl == 8)
-            k_decode_lanes<64, 16, 64, 16, true, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out);
+            k_decode_lanes<64, 16, DRX_DEC_T, 16, true, true><<<nb, 64, lpad, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out);
         else
-            k_decode_lanes<64, 16, 64, 16, true><<<nb, 64, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out);
+            k_decode_lanes<64, 16, DRX_DEC_T, 16, true><<<nb, 64, lpad, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out);
     } else {
         // the lane-per-waveform launch outside the fused form (tables in wave_off / wave_words): `nb` wavefronts of view Gv
         auto launch_lanes = [&](const Geom &Gv, unsigned nb, int im, hipStream_t st_) {
             if (im == 7 && gen)
-                k_decode_lanes<64, 16, 64, 16, false, true, true><<<nb, 64, 0, st_>>>(Gv, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out);
+                k_decode_lanes<64, 16, DRX_DEC_T, 16, false, true, true><<<nb, 64, lpad, st_>>>(Gv, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out);
             else if (im == 7)
-                k_decode_lanes<64, 16, 64, 16, false, true><<<nb, 64, 0, st_>>>(Gv, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out);
+                k_decode_lanes<64, 16, DRX_DEC_T, 16, false, true><<<nb, 64, lpad, st_>>>(Gv, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out);
             else
-                k_decode_lanes<64, 16, 64, 16, false><<<nb, 64, 0, st_>>>(Gv, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out);
+                k_decode_lanes<64, 16, DRX_DEC_T, 16, false><<<nb, 64, lpad, st_>>>(Gv, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out);
         };
         bool lanes_done = false;
         // chunks of short waveforms: stream the chunk through LDS; long waveforms: one dependent load per hop
@@ -2519,7 +2561,11 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                 Gl.rag_groups = G.rag_groups_long;
                 launch_lanes(Gl, Gl.rag_groups, im_split, spw);
             }
-            if (forked && (e = hipEventRecord(side->join, side->s)) != hipSuccess) return e;
+            if (forked && (e = hipEventRecord(side->join, side->s)) != hipSuccess) {
+                // the side stream's kernels write this call's tables and output: never return with them unordered
+                (void)hipStreamSynchronize(side->s);
+                return e;
+            }
             if (use_bw) {
                 // block size: the smallest that exceeds every listed chunk's max_words; wavefronts: what the LDS lets the chip hold
                 const uint32_t max_len = G.uniform ? G.u_wave_len : kWalkShortLen;
@@ -2555,7 +2601,10 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                 launch_lanes(Gs, Gs.rag_groups, im_split, s);
                 lanes_done = true;
             }
-            if (forked && (e = hipStreamWaitEvent(s, side->join, 0)) != hipSuccess) return e;
+            if (forked && (e = hipStreamWaitEvent(s, side->join, 0)) != hipSuccess) {
+                (void)hipStreamSynchronize(side->s);
+                return e;
+            }
             if (impl == 5) impl = 1;
             if (impl == 8) impl = 7;
         } else if (G.uniform) {

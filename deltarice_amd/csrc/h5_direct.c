@@ -45,6 +45,16 @@ static void ensure_filter_registered(void) {
     done = 1;
 }
 
+/* The raw hipMalloc / hipMemcpy calls below must land on the context's device whatever device the calling thread has
+ * current (include/deltarice_hip.h: every call runs on the context's device and restores the caller's). */
+static int enter_device(const drx_ctx *ctx, int *prev) {
+    const int want = drx_ctx_device(ctx);
+    if (hipGetDevice(prev) != hipSuccess) *prev = -1;
+    if (*prev == want) { *prev = -1; return 0; }  /* nothing to restore */
+    return hipSetDevice(want) == hipSuccess ? 0 : -1;
+}
+static void leave_device(int prev) { if (prev >= 0) (void)hipSetDevice(prev); }
+
 static int log2_m(unsigned m, unsigned *k) {
     if (m == 0 || (m & (m - 1)) || m > 32768) return -1;
     *k = 0;
@@ -64,6 +74,8 @@ drx_status drx_h5_read(drx_ctx *ctx, const char *file, const char *name, int16_t
     drx_plan *plan = NULL, *plan_edge = NULL;
     void *d_edge = NULL;
     double t0 = now();
+    int prev_dev = -1;
+    if (enter_device(ctx, &prev_dev) != 0) return DRX_ERR_DEVICE;
 
     if ((f = H5Fopen(file, H5F_ACC_RDONLY, H5P_DEFAULT)) < 0) goto out;
     if ((d = H5Dopen2(f, name, H5P_DEFAULT)) < 0) goto out;
@@ -159,6 +171,7 @@ out:
     if (sp >= 0) H5Sclose(sp);
     if (d >= 0) H5Dclose(d);
     if (f >= 0) H5Fclose(f);
+    leave_device(prev_dev);
     if (st) *st = s;
     return rc;
 }
@@ -189,6 +202,8 @@ drx_status drx_h5_write_filtered(drx_ctx *ctx, const char *file, const char *nam
     uint64_t *d_off = NULL, *h_off = NULL;
     hid_t f = -1, d = -1, sp = -1, pl = -1;
     hipStream_t stream = (hipStream_t)drx_ctx_stream(ctx);
+    int prev_dev = -1;
+    if (enter_device(ctx, &prev_dev) != 0) return DRX_ERR_DEVICE;
 
     double t0 = now();
     uint64_t words = 0, words_e = 0, cap = 0, cap_e = 0;
@@ -258,6 +273,7 @@ out:
     if (d_off) (void)hipFree(d_off);
     if (h_words) (void)hipHostFree(h_words);
     free(h_off);
+    leave_device(prev_dev);
     if (st) *st = s;
     return rc;
 }

@@ -79,6 +79,7 @@ void drx_ctx_destroy(drx_ctx *ctx);
 drx_status drx_ctx_synchronize(drx_ctx *ctx);
 const char *drx_ctx_last_error(const drx_ctx *ctx);
 void *drx_ctx_stream(const drx_ctx *ctx);
+int drx_ctx_device(const drx_ctx *ctx); /* the HIP device the context was created on (-1 for NULL) */
 
 /* Plans.  chunk_wave_len[c] == 0 means "whole chunk" (WaveformLength = -1).
  * Allocates the per-waveform tables and every scratch buffer the batch's geometry can need on the device;

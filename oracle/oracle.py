@@ -21,7 +21,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_ORACLE_SO = os.path.join(_HERE, "libdeltarice_oracle.so")
+# DRO_ORACLE_SO: another build of the same restatement (the sanitizer build of `make -C oracle asan`, tests/test_sanitizers.py)
+_ORACLE_SO = os.environ.get("DRO_ORACLE_SO") or os.path.join(_HERE, "libdeltarice_oracle.so")
 _REF_SO = {
     "omp": os.path.join(_HERE, "_ref", "libdeltarice_ref_omp.so"),
     "serial": os.path.join(_HERE, "_ref", "libdeltarice_ref_serial.so"),

@@ -77,6 +77,26 @@ DEFINE_KERNEL(sad, "v_sad_u32 %0, %0, %1, %2")
 DEFINE_KERNEL(pk_add, "v_pk_add_u16 %0, %0, %1")
 DEFINE_KERNEL(lshlrev_k, "v_lshlrev_b32 %0, 3, %0")
 DEFINE_KERNEL(add_lshl, "v_add_lshl_u32 %0, %0, %1, %2")
+// round 3: which other single-operation instructions are in the fast class
+DEFINE_KERNEL(or_, "v_or_b32 %0, %0, %1")
+DEFINE_KERNEL(xor_, "v_xor_b32 %0, %0, %1")
+DEFINE_KERNEL(ashr, "v_ashrrev_i32 %0, 1, %0")
+DEFINE_KERNEL(mov, "v_mov_b32 %0, %1")
+DEFINE_KERNEL(subrev, "v_subrev_u32 %0, %0, %1")
+DEFINE_KERNEL(xnor, "v_xnor_b32 %0, %0, %1")
+DEFINE_KERNEL(lshr_v, "v_lshrrev_b32 %0, %2, %0")
+DEFINE_KERNEL(add_lit, "v_add_u32 %0, 0x12345, %0")
+DEFINE_KERNEL(and_e64, "v_and_b32_e64 %0, %0, %1")
+DEFINE_KERNEL(add_co, "v_add_co_u32 %0, vcc, %0, %1")
+DEFINE_KERNEL(lshl_or, "v_lshl_or_b32 %0, %0, %2, %1")
+DEFINE_KERNEL(bfi, "v_bfi_b32 %0, %1, %0, %2")
+DEFINE_KERNEL(bitop3, "v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96")
+DEFINE_KERNEL(mul_lo, "v_mul_lo_u32 %0, %0, %1")
+DEFINE_KERNEL(pk_lshr, "v_pk_lshrrev_b16 %0, %2, %0")
+DEFINE_KERNEL(add_sdwa, "v_add_u32_sdwa %0, %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:DWORD")
+DEFINE_KERNEL(min_i, "v_min_i32 %0, %0, %1")
+DEFINE_KERNEL(cvt, "v_cvt_f32_u32 %0, %0")
+DEFINE_KERNEL(addf, "v_add_f32 %0, %0, %1")
 
 typedef void (*kern_t)(uint32_t *, uint32_t, uint64_t *);
 struct Case { const char *name; kern_t dep, ind; };
@@ -86,7 +106,10 @@ int main() {
     const Case cases[] = {CASE(add), CASE(alignbit), CASE(alignbit_k), CASE(bfe), CASE(bfe_k), CASE(lshl_add), CASE(xad), CASE(add3),
                           CASE(and_or), CASE(ffbh), CASE(not_), CASE(lshr), CASE(bfe_i), CASE(cndmask), CASE(cmp), CASE(cndmask_s), CASE(cmp_cnd), CASE(cmp_s_cnd), CASE(max_), CASE(min_), CASE(and_), CASE(sub_),
                           CASE(lshl_v), CASE(lshlrev_k), CASE(mul24), CASE(mad24), CASE(med3), CASE(perm), CASE(or_sdwa), CASE(mov_dpp), CASE(addc),
-                          CASE(sad), CASE(pk_add), CASE(add_lshl)};
+                          CASE(sad), CASE(pk_add), CASE(add_lshl),
+                          CASE(or_), CASE(xor_), CASE(ashr), CASE(mov), CASE(subrev), CASE(xnor), CASE(lshr_v), CASE(add_lit), CASE(and_e64),
+                          CASE(add_co), CASE(lshl_or), CASE(bfi), CASE(bitop3), CASE(mul_lo), CASE(pk_lshr), CASE(add_sdwa), CASE(min_i),
+                          CASE(cvt), CASE(addf)};
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;

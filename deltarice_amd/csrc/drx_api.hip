@@ -362,6 +362,11 @@ drx_status drx_plan_create(drx_ctx *ctx, uint64_t n_chunks, const uint32_t *chun
         p->G.n_short = p->n_short;
         p->G.n_long = p->n_long;
         p->G.max_groups = max_groups;
+        {
+            uint32_t max_len = 0;
+            for (uint64_t c = 0; c < n_chunks; ++c) max_len = std::max(max_len, desc[c].wave_len);
+            p->G.max_wave_len64 = 64ull * max_len;
+        }
         // decode order: wavefronts (groups of 64 waveforms of one chunk) by decreasing WaveformLength
         {
             std::vector<uint32_t> by_len(n_chunks);

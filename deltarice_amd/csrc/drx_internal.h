@@ -52,6 +52,7 @@ struct Geom {
     // (walk_short[n_short], then walk_long[n_long]), and the largest ceil(n_waves / 64) of any chunk
     const uint32_t *walk_short, *walk_long;
     uint32_t n_short, n_long, max_groups;
+    uint64_t max_wave_len64;  // ragged batches: 64 x the longest WaveformLength (how far apart a wavefront's 64 lines can lie)
     // ragged batches that the segment encoder takes (some chunk has short or long waveforms): first unit (waveform x
     // segment slot) of every chunk, n_chunks + 1 entries, and their total
     const uint64_t *seg_unit_base;

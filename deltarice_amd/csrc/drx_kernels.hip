@@ -1828,8 +1828,27 @@ __global__ __launch_bounds__(kLongThreads) void k_decode_long(Geom G, const uint
 //               so the ~1.7 ms of dependent-load latency of the walk disappears behind the decode.
 //               A ticket holder is by construction running, so waiting on a lower ticket's walker
 //               cannot deadlock whatever the dispatch order.  (Uniform batches only.)
-template <int RW, int LW, int T, int GS, bool FUSED, bool PAIR = false, bool GEN = false>
-__global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
+//   NW > 1      STAGED FLUSH (round 3).  What limits the wavefronts per CU is LDS: 16.9 KB of ring + 9.2 KB of transposition
+//               buffer allow six, and at an unchanged instruction stream 6 -> 9 per CU is worth 21 % (profiles/r03_notes.md,
+//               occupancy A/B).  The transposition buffer is needed only while a round's samples change hands, so NW
+//               wavefronts form one workgroup and SHARE one: a wavefront keeps the round's 64 samples per lane in 32
+//               VGPRs (the interior rounds are fully unrolled: static register indices), takes the workgroup's lock
+//               (an LDS compare-and-swap by lane 0), dumps its registers with eight ds_write_b128, reads them back
+//               transposed with eight ds_read_b128, releases the lock and stores whole lines as before.  Rows are 128
+//               bytes without padding; the 16-byte block j of row r lives at block j ^ (r & 7), which makes both the
+//               dump and the transposed read conflict-free.  The rare edge rounds (masked stores, per-sample staging)
+//               hold the lock for the whole round and use the buffer as the private one was used.  NW = 4: two
+//               workgroups = 8 wavefronts per CU; NW = 9: one workgroup = 9 per CU (160 260 of 163 840 bytes).
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int RW, int LW, int T, int GS, bool FUSED, bool PAIR = false, bool GEN = false, int NW = 1>
+__global__ __launch_bounds__(64 * NW, NW == 1 ? 1 : (NW == 4 ? 2 : 3)) void k_decode_lanes(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
                                                      const uint64_t *__restrict__ chunk_word_off,
                                                      uint64_t *__restrict__ wave_off,
                                                      uint32_t *__restrict__ wave_words,
@@ -1840,7 +1859,9 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
 #ifndef DRX_DEC_OPAD
 #define DRX_DEC_OPAD 4
 #endif
-    constexpr int OSW = T / 2 + DRX_DEC_OPAD;  // output row stride in words (16- or 8-byte aligned rows)
+    constexpr bool STG = NW > 1;
+    static_assert(!STG || (PAIR && T == 64 && GS == 16), "the staged flush is built for two samples per access and 64-sample rounds");
+    constexpr int OSW = T / 2 + (STG ? 0 : DRX_DEC_OPAD);  // output row stride in words (16- or 8-byte aligned rows)
     static_assert(OSW % 2 == 0, "rows are read in 8- or 16-byte pieces");
     constexpr int PPS = T / 8;      // 16-byte pieces per stream per round
     constexpr int SPI = 64 / PPS;   // streams per write-out iteration
@@ -1850,8 +1871,11 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
     static_assert(T % GS == 0 && RW - LW >= GS + 2, "round length / ring slack");
     // row r: word w with RW - (w mod RW) == r; row 0 mirrors row RW and row -1 mirrors row RW - 1 (PAIR reads
     // three consecutive words: rows r + 1, r, r - 1)
-    __shared__ uint32_t ring_all[(RW + 2) * 64];
+    __shared__ uint32_t ring_mem[NW][(RW + 2) * 64];
+    const int wv = STG ? (int)(threadIdx.x >> 6) : 0;
+    uint32_t (&ring_all)[(RW + 2) * 64] = ring_mem[wv];
     uint32_t *const ring = ring_all + 64;
+    __shared__ uint32_t fl_lock;  // STG: who holds obuf (0: nobody)
 #ifdef DRX_DEC_NOOBUF  // (ablation builds: no transposition buffer, a lane's sample stores go to four words, no write-out)
     constexpr int OBW = 256;
     constexpr bool kNoObuf = true;
@@ -1866,6 +1890,35 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
 
     const int lane = lane_id();
     const uint32_t k = G.k;
+    if constexpr (STG) {  // (before any wavefront can leave: a walker returns early)
+        if (threadIdx.x == 0) fl_lock = 0u;
+        __syncthreads();
+    }
+    // the workgroup's lock on obuf: taken by lane 0, held by the wavefront.  LDS operations of a wavefront complete in
+    // order, so the holder's reads are done once its s_waitcnt has passed; the holder never waits for another wavefront.
+    auto flush_lock = [&]() __attribute__((always_inline)) {
+        if constexpr (STG) {
+            if (kAblate && (G.dbg & 8u)) return;  // (ablation: no lock -- the samples of neighbouring wavefronts mix)
+            for (;;) {
+                uint32_t got = 1u;
+                if (lane == 0) {
+                    uint32_t expect = 0u;
+                    got = __hip_atomic_compare_exchange_strong(&fl_lock, &expect, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_WORKGROUP) ? 0u : 1u;
+                }
+                if ((uint32_t)__builtin_amdgcn_readfirstlane((int)got) == 0u) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            wave_sync();
+        }
+    };
+    auto flush_unlock = [&]() __attribute__((always_inline)) {
+        if constexpr (STG) {
+            if (kAblate && (G.dbg & 8u)) return;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every read of the buffer has returned
+            if (lane == 0) __hip_atomic_store(&fl_lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
     // Stores go through pointers with an explicit global address space: once `out` has travelled through
     // nested by-reference lambda captures the compiler no longer infers it and emits flat_store, which
     // also ticks lgkmcnt and serialises against the LDS traffic of the write-out (measured: 2x slower).
@@ -1877,6 +1930,7 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
     bool active;
     uint32_t len = 0, n = 0;
     uint64_t S = 1, ooff = 0;
+    const uint32_t wave_idx = STG ? blockIdx.x * (uint32_t)NW + (uint32_t)wv : blockIdx.x;  // (outside the ticketed launch)
     if (FUSED) {
         uint32_t tk = 0;
         if (lane == 0) tk = atomicAdd(ticket, 1u);
@@ -1884,7 +1938,7 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
         // walker tickets first.  Chunks of short waveforms (tens of thousands of hops) are streamed
         // through LDS by a whole wave each (walk_chunk_block, in this wave's ring/transposition LDS),
         // the others are chased through scalar loads, kWalkChains chunks per wave.
-        constexpr bool kBlockWalkFits = sizeof(ring_all) >= kWalkBlockWords * 4u && sizeof(obuf) >= kWalkHopCap * 8u;
+        constexpr bool kBlockWalkFits = !STG && sizeof(ring_all) >= kWalkBlockWords * 4u && sizeof(obuf) >= kWalkHopCap * 8u;
         const bool u_short = G.uniform && G.u_wave_len <= kWalkShortLen;
         const uint32_t n_blockwalk = G.uniform ? (u_short ? (uint32_t)G.n_chunks : 0u) : G.n_short;
         const uint64_t n_chain = G.uniform ? (u_short ? 0ull : G.n_chunks) : (uint64_t)G.n_long;
@@ -1909,6 +1963,7 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
         const uint32_t idx = (uint32_t)grp * 64u + lane;  // waveform index inside chunk c
         uint64_t gr = 0;
         if (G.uniform) {
+            if ((uint32_t)grp * 64u >= G.u_n_waves) return;  // (STG: a ticket beyond the last group)
             active = idx < G.u_n_waves;
             g = c * G.u_n_waves + idx;
             if (active) {
@@ -1946,7 +2001,8 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
         // ragged batch: wavefronts in order of decreasing WaveformLength (longest processing time first).  A lane takes
         // ~60 ns per sample whatever else runs, so a wavefront of 16 384-sample waveforms that starts last adds its
         // whole 1 ms to the launch (config 5: 1.9 -> 1.2 ms)
-        const uint2 e = G.rag_order[blockIdx.x];  // {chunk, group of 64 waveforms inside it}
+        if (wave_idx >= G.rag_groups) return;  // (STG: the last workgroup may have wavefronts to spare)
+        const uint2 e = G.rag_order[wave_idx];  // {chunk, group of 64 waveforms inside it}
         const ChunkDesc d = G.chunks[e.x];
         const uint32_t idx = e.y * 64u + (uint32_t)lane;
         active = idx < d.n_waves;
@@ -1958,7 +2014,7 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
             n = wave_words[g];
         }
     } else {
-        g = (uint64_t)blockIdx.x * 64u + lane;
+        g = (uint64_t)wave_idx * 64u + lane;
         active = g < G.total_waves;
         if (active) {
             const WaveRef r = locate(G, g);
@@ -1970,23 +2026,41 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
     }
     // start delay: step u of every round sits u*2 bytes past a T*2-byte boundary
     const uint32_t phi = active ? (uint32_t)((((uintptr_t)out >> 1) + ooff) & (uint64_t)(T - 1)) : 0u;
-    tab_off[lane] = ooff - phi;
-    tab_lo[lane] = phi;
-    tab_hi[lane] = phi + len;
     const uint32_t steps = wave_max_u32(len + phi);
     const uint32_t lo_max = wave_max_u32(phi);
     const uint32_t hi_min = ~wave_max_u32(~(phi + len));
-    wave_sync();
     uint64_t wo_off[PPS];  // write-out constants: piece p of stream st_i, i = 0..PPS-1
     uint32_t wo_lo[PPS], wo_hi[PPS];
+    // STG: lines are addressed as a wave-uniform base (the line of the wavefront's first waveform: an SGPR pair) plus a
+    // 32-bit offset per lane -- half the registers, and no 64-bit vector adds in front of the stores (the launcher sends
+    // batches whose 64 waveforms could lie 2^31 samples apart to the one-wavefront form)
+    const uint64_t line0 = ooff - phi;
+    const uint64_t line_base = STG ? (((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(line0 >> 32)) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)line0))
+                                   : 0ull;
+    uint32_t wo_rel[PPS];
+    if constexpr (STG) {
 #pragma unroll
-    for (int i = 0; i < PPS; ++i) {
-        const int st = i * SPI + lane / PPS, p = lane % PPS;
-        wo_off[i] = tab_off[st] + 8u * (uint32_t)p;
-        wo_lo[i] = tab_lo[st];
-        wo_hi[i] = tab_hi[st];
+        for (int i = 0; i < PPS; ++i) {
+            const int st = i * SPI + lane / PPS, p = lane % PPS;
+            wo_rel[i] = (uint32_t)__shfl((int)(uint32_t)(line0 - line_base), st) + 8u * (uint32_t)p;
+            wo_off[i] = 0;
+            wo_lo[i] = wo_hi[i] = 0u;
+        }
+    } else {
+        tab_off[lane] = ooff - phi;
+        tab_lo[lane] = phi;
+        tab_hi[lane] = phi + len;
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < PPS; ++i) {
+            const int st = i * SPI + lane / PPS, p = lane % PPS;
+            wo_off[i] = tab_off[st] + 8u * (uint32_t)p;
+            wo_lo[i] = tab_lo[st];
+            wo_hi[i] = tab_hi[st];
+        }
+        wave_sync();
     }
-    wave_sync();
 
     const uint64_t A = (S & ~(uint64_t)(RW - 1)) - (uint64_t)RW;  // s0 in [RW, 2 RW)
     const uint32_t s0 = (uint32_t)(S - A);
@@ -2002,6 +2076,14 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
     u16a *myout = reinterpret_cast<u16a *>(obuf + lane * OSW);
 #define DRX_OIDX(x) (x)
 #endif
+    // the round's whole-line stores (A/B: -DDRX_DEC_NT_STORE marks them non-temporal)
+    auto store16 = [&](g_i16 *dst, const uint4 &v) __attribute__((always_inline)) {
+#ifdef DRX_DEC_NT_STORE
+        __builtin_nontemporal_store((u32x4v){v.x, v.y, v.z, v.w}, (g_uint4 *)dst);
+#else
+        *(g_uint4 *)dst = (u32x4v){v.x, v.y, v.z, v.w};
+#endif
+    };
     // 16 bytes of a stream's row: one ds_read_b128 where the rows are 16-byte aligned, else two ds_read_b64
     auto orow16 = [&](int st, int p) __attribute__((always_inline)) -> uint4 {
         if constexpr (OSW % 4 == 0) {
@@ -2106,9 +2188,11 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
     // step of a lane lies in an edge round or is the last step of an interior round: only those capture.
     const uint32_t hi_step = phi + len;  // this lane decodes its last sample in step hi_step - 1
     uint32_t Q_end = 0;
-    auto decode_group = [&](auto first_tag, auto edge_tag, int tg, uint32_t tcur) __attribute__((always_inline)) {
+    uint32_t stg[STG ? T / 2 : 1];  // STG: the round's samples of this lane, two per dword (interior rounds)
+    auto decode_group = [&](auto first_tag, auto edge_tag, auto stg_tag, int tg, uint32_t tcur) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_tag)::value;
         constexpr bool EDGE = decltype(edge_tag)::value;  // tcur + u is the step index; capture Q_end
+        constexpr int TGC = decltype(stg_tag)::value;     // >= 0: tg at compile time, samples go to stg[] (interior rounds of STG)
         if (PAIR && !FIRST) {
             // two samples per ring access: a 64-bit window (three words) always holds two codes (2 x 25 bits),
             // so the second sample's window is one v_alignbit away from the first one's length -- one LDS
@@ -2139,7 +2223,10 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
                 const uint32_t a1 = (uint32_t)acc;
                 advance((int32_t)(z2 >> 1) ^ -(int32_t)(z2 & 1u));
                 // low halves of the two running sums in one v_perm_b32
-                *reinterpret_cast<uint32_t *>(myout + DRX_OIDX(tg + u)) = __builtin_amdgcn_perm((uint32_t)acc, a1, 0x05040100u);
+                if constexpr (TGC >= 0)
+                    stg[(TGC + u) / 2] = __builtin_amdgcn_perm((uint32_t)acc, a1, 0x05040100u);
+                else
+                    *reinterpret_cast<uint32_t *>(myout + DRX_OIDX(tg + u)) = __builtin_amdgcn_perm((uint32_t)acc, a1, 0x05040100u);
             }
             return;
         }
@@ -2169,10 +2256,31 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
                 Q -= used;
             }
             if constexpr (EDGE) Q_end = (tcur + (uint32_t)u + 1u == hi_step) ? Q : Q_end;
-            myout[DRX_OIDX(tg + u)] = (uint16_t)acc;
+            if constexpr (TGC >= 0) {  // (two steps fill a staging dword)
+                if ((u & 1) == 0) stg[(TGC + u) / 2] = (uint32_t)acc & 0xffffu;
+                else stg[(TGC + u) / 2] |= (uint32_t)acc << 16;
+            } else {
+                myout[DRX_OIDX(tg + u)] = (uint16_t)acc;
+            }
         }
     };
 
+    // piece i of an EDGE round (first / last rounds of a waveform): only the samples that belong to the stream
+    auto emit_masked = [&](g_i16 *dst, uint32_t lo, uint32_t hi, uint32_t t0, const uint4 &v) __attribute__((always_inline)) {
+        const int p = lane % PPS;
+        const uint32_t tpos = t0 + 8u * (uint32_t)p;  // step index of the piece's first sample
+        if (tpos + 8u > lo && tpos < hi) {
+            if (tpos >= lo && tpos + 8u <= hi) {
+                *(g_uint4 *)dst = (u32x4v){v.x, v.y, v.z, v.w};
+            } else {
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (tpos + (uint32_t)j >= lo && tpos + (uint32_t)j < hi)
+                        dst[j] = (int16_t)(w[j >> 1] >> (16 * (j & 1)));
+            }
+        }
+    };
     auto write_out = [&](uint32_t t0) __attribute__((always_inline)) {
         if (kNoObuf || (kAblate && (G.dbg & 1u))) return;
         if (t0 >= lo_max && t0 + T <= hi_min) {  // interior round: whole aligned lines only
@@ -2180,39 +2288,82 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
             for (int i = 0; i < PPS; ++i) {
                 const int st = i * SPI + lane / PPS, p = lane % PPS;
                 const uint4 v = orow16(st, p);
-                *(g_uint4 *)(outg + wo_off[i] + t0) = (u32x4v){v.x, v.y, v.z, v.w};
+                store16(outg + wo_off[i] + t0, v);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < PPS; ++i) {
                 const int st = i * SPI + lane / PPS, p = lane % PPS;
-                const uint32_t tpos = t0 + 8u * (uint32_t)p;  // step index of the piece's first sample
-                if (tpos + 8u > wo_lo[i] && tpos < wo_hi[i]) {
-                    const uint4 v = orow16(st, p);
-                    g_i16 *dst = outg + wo_off[i] + t0;
-                    if (tpos >= wo_lo[i] && tpos + 8u <= wo_hi[i]) {
-                        *(g_uint4 *)dst = (u32x4v){v.x, v.y, v.z, v.w};
-                    } else {
-                        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                const uint32_t tpos = t0 + 8u * (uint32_t)p;
+                if (tpos + 8u > wo_lo[i] && tpos < wo_hi[i]) emit_masked(outg + wo_off[i] + t0, wo_lo[i], wo_hi[i], t0, orow16(st, p));
+            }
+        }
+    };
+    // STG: the round's samples change hands through the workgroup's buffer: rows of 128 bytes, block j of row r at block
+    // j ^ (r & 7) (conflict-free both ways); nothing but these sixteen LDS operations happens under the lock
+    auto flush_exchange = [&](uint4 (&ov)[PPS]) __attribute__((always_inline)) {
+        if constexpr (STG) {
+            const uint32_t rowx = (uint32_t)lane * 32u + (uint32_t)(lane & 7) * 4u;
+            const uint32_t rd = (uint32_t)(lane >> 3) * 32u + 4u * (uint32_t)((lane & 7) ^ (lane >> 3));
+            flush_lock();
 #pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            if (tpos + (uint32_t)j >= wo_lo[i] && tpos + (uint32_t)j < wo_hi[i])
-                                dst[j] = (int16_t)(w[j >> 1] >> (16 * (j & 1)));
-                    }
-                }
+            for (int j = 0; j < T / 8; ++j)
+                *reinterpret_cast<uint4 *>(obuf + (rowx ^ (4u * (uint32_t)j))) = make_uint4(stg[4 * j], stg[4 * j + 1], stg[4 * j + 2], stg[4 * j + 3]);
+            wave_sync();
+#pragma unroll
+            for (int i = 0; i < PPS; ++i) ov[i] = *reinterpret_cast<const uint4 *>(obuf + (uint32_t)i * 256u + rd);
+            flush_unlock();
+        }
+    };
+    // the samples of the group that ends here are final (see the interior loop)
+    auto pin_group = [&](auto gi) __attribute__((always_inline)) {
+        if constexpr (STG) {
+            constexpr int TG = decltype(gi)::value * GS;
+            int32_t &a_ = acc;  // (named here so that the generic lambda captures them: asm operands alone do not)
+            uint32_t (&s_)[STG ? T / 2 : 1] = stg;
+            asm volatile("" : "+v"(a_), "+v"(s_[TG / 2]), "+v"(s_[TG / 2 + 1]), "+v"(s_[TG / 2 + 2]), "+v"(s_[TG / 2 + 3]),
+                         "+v"(s_[TG / 2 + 4]), "+v"(s_[TG / 2 + 5]), "+v"(s_[TG / 2 + 6]), "+v"(s_[TG / 2 + 7]));
+        }
+    };
+    auto stg_line = [&](int i, uint32_t t0) __attribute__((always_inline)) -> g_i16 * {  // piece i of this lane in round t0
+        return (outg + line_base + t0) + wo_rel[i];
+    };
+    auto stg_edge_out = [&](uint32_t t0) __attribute__((always_inline)) {  // STG: an edge round's masked write-out
+        uint4 ov[PPS];
+        flush_exchange(ov);
+        if (kAblate && (G.dbg & 1u)) return;
+        if (t0 >= lo_max && t0 + T <= hi_min) {
+#pragma unroll
+            for (int i = 0; i < PPS; ++i) store16(stg_line(i, t0), ov[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < PPS; ++i) {  // (the stream's limits come by shuffle: edge rounds are 2-3 of ~110)
+                const int st = i * SPI + lane / PPS;
+                emit_masked(stg_line(i, t0), (uint32_t)__shfl((int)phi, st), (uint32_t)__shfl((int)(phi + len), st), t0, ov[i]);
             }
         }
     };
 
     // round 0 (start delays; synchronous refills; runs once)
     if (steps > 0) {
+        if constexpr (STG) {
+            static_for<0, T / GS>([&](auto gi) __attribute__((always_inline)) {
+                constexpr int TG = decltype(gi)::value * GS;
+                sync_refill();
+                decode_group(std::true_type{}, std::true_type{}, std::integral_constant<int, TG>{}, TG, (uint32_t)TG);
+                pin_group(gi);
+            });
+            wave_sync();
+            stg_edge_out(0);
+        } else {
 #pragma unroll 1
-        for (int tg = 0; tg < T; tg += GS) {
-            sync_refill();
-            decode_group(std::true_type{}, std::true_type{}, tg, (uint32_t)tg);
+            for (int tg = 0; tg < T; tg += GS) {
+                sync_refill();
+                decode_group(std::true_type{}, std::true_type{}, std::integral_constant<int, -1>{}, tg, (uint32_t)tg);
+            }
+            wave_sync();
+            write_out(0);
         }
-        wave_sync();
-        write_out(0);
         wave_sync();
     }
 
@@ -2226,13 +2377,24 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
     // that the compiler's waitcnt insertion can prove the count.  Up to two pieces per lane and round
     // (2 LW words = 16 bits per sample at LW = 16); hungrier streams fall back to sync_refill().
     auto edge_round = [&](uint32_t t0) __attribute__((always_inline)) {  // first / last rounds: masked stores, synchronous refills
+        if constexpr (STG) {
+            static_for<0, T / GS>([&](auto gi) __attribute__((always_inline)) {
+                constexpr int TG = decltype(gi)::value * GS;
+                sync_refill();
+                decode_group(std::false_type{}, std::true_type{}, std::integral_constant<int, TG>{}, TG, t0 + (uint32_t)TG);
+                pin_group(gi);
+            });
+            wave_sync();
+            stg_edge_out(t0);
+        } else {
 #pragma unroll 1
-        for (int tg = 0; tg < T; tg += GS) {
-            sync_refill();
-            decode_group(std::false_type{}, std::true_type{}, tg, t0 + (uint32_t)tg);
+            for (int tg = 0; tg < T; tg += GS) {
+                sync_refill();
+                decode_group(std::false_type{}, std::true_type{}, std::integral_constant<int, -1>{}, tg, t0 + (uint32_t)tg);
+            }
+            wave_sync();
+            write_out(t0);
         }
-        wave_sync();
-        write_out(t0);
         wave_sync();
     };
     uint32_t t0 = T;
@@ -2242,30 +2404,45 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
     uint4 pv0[NV], pv1[NV];               // pieces in flight
     bool pneed0 = false, pneed1 = false;  // this lane has them in flight
     set_limits();
-    for (; t0 + T <= hi_min && t0 < steps; t0 += T) {  // interior rounds
-#pragma unroll 1
-        for (int tg = 0; tg < T; tg += GS) {
-            if (__any((int32_t)(Q - Q_need) <= 0)) {  // one signed compare per test (positions are mod 2^32)
-                // a piece in flight was requested counting on the words this round consumes at least
-                // (min_words): before the round is over it may only be committed where it already fits
-                uint32_t avail = (flw - ((~Q) >> 5)) & WMASK;
-                if (pneed0 && avail <= (uint32_t)(RW - LW)) {
-                    store_piece(pv0);
-                    pneed0 = false;
-                    avail += (uint32_t)LW;
-                    if (pneed1 && avail <= (uint32_t)(RW - LW)) { store_piece(pv1); pneed1 = false; }
-                }
-                if (!pneed0 && pneed1) {
-#pragma unroll
-                    for (int j = 0; j < NV; ++j) pv0[j] = pv1[j];
-                    pneed0 = true;
-                    pneed1 = false;
-                }
-                wave_sync();
-                sync_refill();
-                set_limits();
+    auto group_refill = [&]() __attribute__((always_inline)) {
+        if (__any((int32_t)(Q - Q_need) <= 0)) {  // one signed compare per test (positions are mod 2^32)
+            // a piece in flight was requested counting on the words this round consumes at least
+            // (min_words): before the round is over it may only be committed where it already fits
+            uint32_t avail = (flw - ((~Q) >> 5)) & WMASK;
+            if (pneed0 && avail <= (uint32_t)(RW - LW)) {
+                store_piece(pv0);
+                pneed0 = false;
+                avail += (uint32_t)LW;
+                if (pneed1 && avail <= (uint32_t)(RW - LW)) { store_piece(pv1); pneed1 = false; }
             }
-            decode_group(std::false_type{}, std::false_type{}, tg, 0u);
+            if (!pneed0 && pneed1) {
+#pragma unroll
+                for (int j = 0; j < NV; ++j) pv0[j] = pv1[j];
+                pneed0 = true;
+                pneed1 = false;
+            }
+            wave_sync();
+            sync_refill();
+            set_limits();
+        }
+    };
+    for (; t0 + T <= hi_min && t0 < steps; t0 += T) {  // interior rounds
+        if constexpr (STG) {  // fully unrolled: the staging registers are indexed at compile time
+            static_for<0, T / GS>([&](auto gi) __attribute__((always_inline)) {
+                constexpr int TG = decltype(gi)::value * GS;
+                group_refill();
+                decode_group(std::false_type{}, std::false_type{}, std::integral_constant<int, TG>{}, TG, 0u);
+                // the group's values are final HERE: without this the compiler runs the bit-position chain of the whole
+                // unrolled round ahead (the next group's refill test needs only that) and parks every window, quotient and
+                // width of sixteen samples in registers until it gets round to the values: 415 VGPRs and 350 spills
+                pin_group(gi);
+            });
+        } else {
+#pragma unroll 1
+            for (int tg = 0; tg < T; tg += GS) {
+                group_refill();
+                decode_group(std::false_type{}, std::false_type{}, std::integral_constant<int, -1>{}, tg, 0u);
+            }
         }
         Q_end = (t0 + (uint32_t)T == hi_step) ? Q : Q_end;  // a lane whose last step closes an interior round
         wave_sync();
@@ -2283,12 +2460,19 @@ __global__ __launch_bounds__(64) void k_decode_lanes(Geom G, const uint32_t *__r
             if (pneed0) load_piece(pv0);
             if (pneed1) load_piece(pv1, (uint32_t)LW);
         }
-        if (!(kNoObuf || (kAblate && (G.dbg & 1u)))) {
+        if constexpr (STG) {
+            uint4 ov[PPS];
+            flush_exchange(ov);
+            if (!(kAblate && (G.dbg & 1u))) {
+#pragma unroll
+                for (int i = 0; i < PPS; ++i) store16(stg_line(i, t0), ov[i]);
+            }
+        } else if (!(kNoObuf || (kAblate && (G.dbg & 1u)))) {
 #pragma unroll
             for (int i = 0; i < PPS; ++i) {  // whole aligned lines only
                 const int st = i * SPI + lane / PPS, p = lane % PPS;
                 const uint4 v = orow16(st, p);
-                *(g_uint4 *)(outg + wo_off[i] + t0) = (u32x4v){v.x, v.y, v.z, v.w};
+                store16(outg + wo_off[i] + t0, v);
             }
         }
         wave_sync();
@@ -2458,6 +2642,9 @@ static unsigned dec_lds_pad() {
 #ifndef DRX_DEC_T
 #define DRX_DEC_T 64
 #endif
+#ifndef DRX_DEC_LW
+#define DRX_DEC_LW 16
+#endif
 hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                          const uint64_t *d_chunk_word_off, int16_t *d_out, uint64_t *d_wave_off,
                          uint32_t *d_wave_words, uint64_t *d_granules, DevStatus *d_status, int impl,
@@ -2503,21 +2690,35 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
             groups = G.max_groups;
         }
         const unsigned nb = n_walk + (unsigned)(G.n_chunks * groups);
-        if (impl == 8 && gen)
-            k_decode_lanes<64, 16, DRX_DEC_T, 16, true, true, true><<<nb, 64, lpad, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out);
+#ifndef DRX_DEC_NW
+#define DRX_DEC_NW 1
+#endif
+        // staged flush (NW wavefronts share one transposition buffer: 8 or 9 wavefronts per CU instead of 6); its walker
+        // role has no LDS to stream short-waveform chunks through, those batches keep the one-wavefront form
+        constexpr int NWs = DRX_DEC_NW;
+        const bool short_walk = G.uniform ? G.u_wave_len <= kWalkShortLen : G.n_short != 0;
+        const bool lines_near = G.uniform ? (uint64_t)G.u_wave_len * 64u < (1ull << 31) : G.max_wave_len64 < (1ull << 31);
+        if (NWs > 1 && impl == 8 && !short_walk && lines_near && !(G.dbg & 1048576u)) {
+            const unsigned nwg = (nb + NWs - 1u) / NWs;
+            if (gen)
+                k_decode_lanes<64, DRX_DEC_LW, 64, 16, true, true, true, NWs><<<nwg, 64 * NWs, lpad, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out);
+            else
+                k_decode_lanes<64, DRX_DEC_LW, 64, 16, true, true, false, NWs><<<nwg, 64 * NWs, lpad, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out);
+        } else if (impl == 8 && gen)
+            k_decode_lanes<64, DRX_DEC_LW, DRX_DEC_T, 16, true, true, true><<<nb, 64, lpad, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out);
         else if (impl == 8)
-            k_decode_lanes<64, 16, DRX_DEC_T, 16, true, true><<<nb, 64, lpad, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out);
+            k_decode_lanes<64, DRX_DEC_LW, DRX_DEC_T, 16, true, true><<<nb, 64, lpad, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out);
         else
-            k_decode_lanes<64, 16, DRX_DEC_T, 16, true><<<nb, 64, lpad, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out);
+            k_decode_lanes<64, DRX_DEC_LW, DRX_DEC_T, 16, true><<<nb, 64, lpad, s>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, d_granules, ticket, d_status, d_out);
     } else {
         // the lane-per-waveform launch outside the fused form (tables in wave_off / wave_words): `nb` wavefronts of view Gv
         auto launch_lanes = [&](const Geom &Gv, unsigned nb, int im, hipStream_t st_) {
             if (im == 7 && gen)
-                k_decode_lanes<64, 16, DRX_DEC_T, 16, false, true, true><<<nb, 64, lpad, st_>>>(Gv, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out);
+                k_decode_lanes<64, DRX_DEC_LW, DRX_DEC_T, 16, false, true, true><<<nb, 64, lpad, st_>>>(Gv, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out);
             else if (im == 7)
-                k_decode_lanes<64, 16, DRX_DEC_T, 16, false, true><<<nb, 64, lpad, st_>>>(Gv, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out);
+                k_decode_lanes<64, DRX_DEC_LW, DRX_DEC_T, 16, false, true><<<nb, 64, lpad, st_>>>(Gv, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out);
             else
-                k_decode_lanes<64, 16, DRX_DEC_T, 16, false><<<nb, 64, lpad, st_>>>(Gv, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out);
+                k_decode_lanes<64, DRX_DEC_LW, DRX_DEC_T, 16, false><<<nb, 64, lpad, st_>>>(Gv, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out);
         };
         bool lanes_done = false;
         // chunks of short waveforms: stream the chunk through LDS; long waveforms: one dependent load per hop

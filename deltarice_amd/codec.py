@@ -94,8 +94,10 @@ class Context:
             self._check(self.lib.drx_plan_set_filter(h, o.n_taps, o.taps))
         return plan
 
-    def plan(self, chunk_samples: Sequence[int], wave_lens: Sequence[int], rice_m: int = 8) -> "Plan":
-        """Ragged batch: per-chunk sample counts and WaveformLengths (0 or -1: whole chunk)."""
+    def plan(self, chunk_samples: Sequence[int], wave_lens: Sequence[int], rice_m: int = 8,
+             taps: Optional[Sequence[int]] = None) -> "Plan":
+        """Ragged batch: per-chunk sample counts and WaveformLengths (0 or -1: whole chunk); taps: a general
+        prediction filter for every chunk (compression_opts[3:] of the reference), None: the delta filter."""
         o = parse_opts((rice_m,))
         n = len(chunk_samples)
         if n == 0 or len(wave_lens) != n:
@@ -104,7 +106,11 @@ class Context:
         wl = (C.c_uint32 * n)(*[0 if int(v) <= 0 else int(v) for v in wave_lens])
         h = C.c_void_p()
         self._check(self.lib.drx_plan_create(self._h, n, cs, wl, o.rice_k, C.byref(h)))
-        return Plan(self, h)
+        plan = Plan(self, h)
+        if taps is not None:
+            t = (C.c_int32 * len(taps))(*[int(v) for v in taps])
+            self._check(self.lib.drx_plan_set_filter(h, len(taps), t))
+        return plan
 
     def filter_chunk(self, data: bytes | np.ndarray, opts: Sequence[int] = (), reverse: bool = False) -> bytes:
         """One chunk through host memory with the H5Z callback's semantics
@@ -206,6 +212,10 @@ class Plan:
         ms = (C.c_float * 4)()
         self.ctx._check(self.ctx.lib.drx_plan_last_timings(self._h, ms))
         return tuple(float(v) for v in ms)
+
+    def last_decode_path(self) -> int:
+        """DRX_PATH_* bits (include/deltarice_hip.h) of the decoders the last decode used."""
+        return int(self.ctx.lib.drx_plan_last_decode_path(self._h))
 
     def wave_words(self) -> np.ndarray:
         """n_i (payload words) of every waveform from the last encode/decode, on the host."""

@@ -88,10 +88,15 @@ struct drx_plan {
     void *d_blk = nullptr;             // few waveforms: unit table, look-back state and flags of the block-parallel decoder
     uint32_t *d_walk_lists = nullptr;  // ragged plans: chunk indices, short-waveform chunks first
     uint2 *d_rag_order = nullptr;      // ragged plans: decode wavefronts, longest WaveformLength first
+    uint32_t *d_iir_tab = nullptr;     // general filter behind the block decoder (drx_iir.hip): matrix tables of the plan's filter,
+    uint64_t *d_iir_state = nullptr;   // look-back state of its tiles (+ ticket), and (ragged plans) the first tile of every chunk
+    uint64_t *d_iir_chunk_base = nullptr;
+    uint32_t *d_blk_list = nullptr;    // ragged plans the block decoder takes: waveform indices, class by class
     uint32_t n_short = 0, n_long = 0;
     DevStatus *d_status = nullptr;
     DevStatus *h_status = nullptr;  // pinned
     bool last_was_encode = false;
+    uint32_t last_path = 0;  // DRX_PATH_* of the last decode
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
 };
@@ -259,6 +264,10 @@ static void plan_free(drx_plan *p) {
     if (p->d_taps) (void)hipFree(p->d_taps);
     if (p->d_walk_lists) (void)hipFree(p->d_walk_lists);
     if (p->d_rag_order) (void)hipFree(p->d_rag_order);
+    if (p->d_iir_tab) (void)hipFree(p->d_iir_tab);
+    if (p->d_iir_state) (void)hipFree(p->d_iir_state);
+    if (p->d_iir_chunk_base) (void)hipFree(p->d_iir_chunk_base);
+    if (p->d_blk_list) (void)hipFree(p->d_blk_list);
     if (p->d_seg_bits) (void)hipFree(p->d_seg_bits);
     if (p->d_seg_pos) (void)hipFree(p->d_seg_pos);
     if (p->d_seg_unit_base) (void)hipFree(p->d_seg_unit_base);
@@ -295,7 +304,13 @@ static drx_status plan_alloc_scratch(drx_ctx *ctx, drx_plan *p) {
         DRX_HIP(ctx, hipMalloc((void **)&p->d_seg_pos, units * sizeof(uint64_t)));
     }
     if (const uint64_t nb = par_walk_scratch_bytes(p->G)) DRX_HIP(ctx, hipMalloc(&p->d_pw, nb));
-    if (const uint64_t nb = blocks_scratch_bytes(p->G)) DRX_HIP(ctx, hipMalloc(&p->d_blk, nb));
+    if (const uint64_t nb = blocks_scratch_bytes(p->G)) {
+        DRX_HIP(ctx, hipMalloc(&p->d_blk, nb));
+        // ... and, should the plan get a general prediction filter, the look-back state of the in-place inverse filter
+        if (p->G.uniform) p->G.iir_n_tiles = iir_tiles(p->G, nullptr, nullptr);
+        DRX_HIP(ctx, hipMalloc((void **)&p->d_iir_state, (p->G.iir_n_tiles + 1) * sizeof(uint64_t)));
+        p->G.iir_state = p->d_iir_state;
+    }
     if (p->G.uniform) {  // the pieces encoder's workgroups, where the geometry is one it can take (pieces_batch() decides per call)
         const uint32_t L = p->G.u_wave_len;
         const PieceShape sh = piece_shape(L, p->G.u_n_waves, piece_packable(L));
@@ -448,6 +463,19 @@ drx_status drx_plan_create(drx_ctx *ctx, uint64_t n_chunks, const uint32_t *chun
                 p->pc_wgs = wgs;
             }
         }
+        // few long waveforms: the block-parallel decoder (and, behind it, the in-place inverse of a general filter)
+        std::vector<uint32_t> blk_list(wbase ? wbase : 1);
+        blocks_plan_ragged(p->G, desc.data(), blk_list.data());
+        if (p->G.rag_blocks) {
+            if (e == hipSuccess) e = hipMalloc((void **)&p->d_blk_list, blk_list.size() * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMemcpy(p->d_blk_list, blk_list.data(), blk_list.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            p->G.rag_blk_list = p->d_blk_list;
+            std::vector<uint64_t> tb(n_chunks + 1, 0);
+            p->G.iir_n_tiles = iir_tiles(p->G, desc.data(), tb.data());
+            if (e == hipSuccess) e = hipMalloc((void **)&p->d_iir_chunk_base, tb.size() * sizeof(uint64_t));
+            if (e == hipSuccess) e = hipMemcpy(p->d_iir_chunk_base, tb.data(), tb.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
+            p->G.iir_chunk_tile_base = p->d_iir_chunk_base;
+        }
         if (e != hipSuccess) st = fail(ctx, DRX_ERR_DEVICE, "chunk table upload failed: %s", hipGetErrorString(e));
     }
     if (st != DRX_OK) { plan_free(p); return st; }
@@ -499,6 +527,7 @@ drx_status drx_plan_set_filter(drx_plan *p, uint32_t n_taps, const int32_t *taps
     if (n_taps == 2 && taps[0] == 1 && taps[1] == -1) {  // checkIfDeltaFilter, src/deltaRice.c:38-46
         p->G.n_taps = 0;
         p->G.taps = nullptr;
+        p->G.iir_tab = nullptr;
         return DRX_OK;
     }
     if (n_taps <= 4) {
@@ -509,6 +538,14 @@ drx_status drx_plan_set_filter(drx_plan *p, uint32_t n_taps, const int32_t *taps
         p->G.fast_taps = 1;
         p->G.fast_t0neg = taps[0] == -1;
         for (uint32_t j = 1; j < 4; ++j) p->G.fast_nt[j - 1] = (j < n_taps) ? 0u - (uint32_t)taps[j] : 0u;
+    }
+    p->G.iir_tab = nullptr;
+    if (p->G.fast_taps && p->d_iir_state) {  // the block decoder's geometry: the inverse filter's matrix tables
+        std::vector<uint32_t> tab(kIirTabWords);
+        iir_tables(p->G.fast_nt, p->G.fast_t0neg, tab.data());
+        if (!p->d_iir_tab) DRX_HIP(ctx, hipMalloc((void **)&p->d_iir_tab, kIirTabWords * sizeof(uint32_t)));
+        DRX_HIP(ctx, hipMemcpy(p->d_iir_tab, tab.data(), kIirTabWords * sizeof(uint32_t), hipMemcpyHostToDevice));
+        p->G.iir_tab = p->d_iir_tab;
     }
     if (!p->d_taps) DRX_HIP(ctx, hipMalloc((void **)&p->d_taps, DRX_MAX_TAPS * sizeof(int32_t)));
     DRX_HIP(ctx, hipMemcpy(p->d_taps, taps, n_taps * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -524,6 +561,7 @@ uint64_t drx_plan_total_waves(const drx_plan *p) { return p ? p->G.total_waves :
 uint64_t drx_plan_max_encoded_words(const drx_plan *p) { return p ? p->max_words : 0; }
 const uint32_t *drx_plan_wave_words(const drx_plan *p) { return p ? p->d_wave_words : nullptr; }
 const uint64_t *drx_plan_wave_word_off(const drx_plan *p) { return p ? p->d_wave_off : nullptr; }
+uint32_t drx_plan_last_decode_path(const drx_plan *p) { return p ? p->last_path : 0u; }
 
 drx_status drx_plan_read_wave_words(drx_plan *p, uint32_t *host_out) {
     if (!p || !host_out) return DRX_ERR_ARG;
@@ -578,7 +616,7 @@ static drx_status decode_launch(drx_plan *p, const uint32_t *d_in, uint64_t in_w
     DRX_HIP(ctx, launch_decode(p->G, d_in, in_words, d_chunk_word_off, d_out, p->d_wave_off,
                                p->d_wave_words, p->d_scan, p->d_status,
                                (tables_ready ? 100 : 0) + ctx->decode_impl, p->d_pw, p->d_blk, ctx->side.s ? &ctx->side : nullptr,
-                               ctx->profile ? p->ev : nullptr, ctx->stream));
+                               ctx->profile ? p->ev : nullptr, ctx->stream, &p->last_path));
     p->ev_valid = ctx->profile != 0;
     p->last_was_encode = false;
     return DRX_OK;

@@ -37,6 +37,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <type_traits>
 
 #include "drx_device.h"
 #include "drx_internal.h"
@@ -66,13 +67,15 @@ __host__ __device__ inline uint32_t blk_words(uint32_t nt) { return nt * kBlkSeg
 
 // Most blocks any waveform of the batch has: info[0]; tickets of the decode launch: info[1] = info[0] x waveforms.
 // One workgroup.
+// (list: the waveforms of this launch, nullptr = all of them in order)
 __global__ __launch_bounds__(1024) void k_blk_max(uint64_t total_waves, const uint32_t *__restrict__ wave_words,
-                                                  uint32_t words_per_block, uint32_t *__restrict__ info) {
+                                                  uint32_t words_per_block, uint32_t *__restrict__ info,
+                                                  const uint32_t *__restrict__ list) {
     __shared__ uint32_t wmax[16];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     uint32_t m = 0;
     for (uint64_t i = threadIdx.x; i < total_waves; i += 1024) {
-        const uint32_t v = (wave_words[i] + words_per_block - 1u) / words_per_block;
+        const uint32_t v = (wave_words[list ? list[i] : i] + words_per_block - 1u) / words_per_block;
         m = v > m ? v : m;
     }
     m = wave_max_u32(m);
@@ -155,7 +158,9 @@ __device__ __forceinline__ uint32_t unzigzag(uint32_t z) { return (z >> 1) ^ (0u
 // A lane that is not enabled keeps its state.  (A variant that ran a wave without per-code masks while every lane had
 // room for two more codes, and only the last few codes masked, was measured 4-8 % SLOWER: the vote per pair and the
 // second loop cost what the masks had: profiles/r02_notes.md.)
-template <int MODE>
+// RESID: the RESIDUALS themselves are staged / stored instead of their running sums (general prediction filters: the inverse
+// filter runs afterwards, in place, k_iir_tiles).
+template <int MODE, bool RESID = false>
 __device__ __forceinline__ void blk_parse(const uint32_t *W, uint32_t k, bool enable, uint32_t &Qp, uint32_t qlim,
                                           uint32_t &c, uint32_t &sum, uint32_t cmax, uint16_t *outp, uint32_t *stage = nullptr) {
     auto more = [&](uint32_t q, uint32_t cc) __attribute__((always_inline)) {
@@ -173,8 +178,8 @@ __device__ __forceinline__ void blk_parse(const uint32_t *W, uint32_t k, bool en
                 if (act2 && p.pad2) { act2 = false; qlim = Qa; }
             }
             if (MODE != kBlkSkip) {
-                const uint32_t s1 = sum + unzigzag(p.z1);
-                const uint32_t s2 = s1 + unzigzag(p.z2);
+                const uint32_t s1 = RESID ? unzigzag(p.z1) : sum + unzigzag(p.z1);
+                const uint32_t s2 = RESID ? unzigzag(p.z2) : s1 + unzigzag(p.z2);
                 if (MODE == kBlkValue) {
                     if (act1) outp[c] = (uint16_t)s1;
                     if (act2) outp[c + 1u] = (uint16_t)s2;
@@ -191,7 +196,7 @@ __device__ __forceinline__ void blk_parse(const uint32_t *W, uint32_t k, bool en
     }
 }
 
-template <int NT>
+template <int NT, bool RESID = false>
 __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
                                                       const uint64_t *__restrict__ wave_off,
                                                       const uint32_t *__restrict__ wave_words,
@@ -199,7 +204,8 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
                                                       uint32_t run_len, uint64_t *__restrict__ state,
                                                       uint32_t *__restrict__ ends, uint32_t *__restrict__ ticket,
                                                       uint32_t *__restrict__ fail, uint32_t *__restrict__ suspect,
-                                                      DevStatus *st, int16_t *__restrict__ out, unsigned long long *prof) {
+                                                      DevStatus *st, int16_t *__restrict__ out, unsigned long long *prof,
+                                                      const uint32_t *__restrict__ wave_list, uint32_t n_list) {
     using BG = BlkGeom<NT>;
     constexpr uint32_t K = BG::kLdsWords + 2u;  // word w of the image sits at W[K + 1 - w]; K = 2 (mod 4): 16-byte quads
     constexpr uint32_t C = 32u * K;
@@ -228,7 +234,9 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
     // In-kernel stamps of the first version (a ticket per block, waveform-major: 768 blocks of ONE 14 M-sample waveform
     // in flight, every one polling twelve windows of aggregates) had 11 % of a workgroup's time in the parse and 77 % in
     // four waits: ticket, image, predecessor's end, look-back (profiles/r02_notes.md).
-    const uint32_t n_waves32 = (uint32_t)G.total_waves;
+    // the waveforms of THIS launch: all of the batch, or (ragged batches) those of one length class -- tickets are dealt
+    // run-major over them, and a class whose waveforms differ by less than 2x in length wastes few tickets on empty runs
+    const uint32_t n_waves32 = wave_list ? n_list : (uint32_t)G.total_waves;
     const uint32_t max_runs = (info[0] + run_len - 1u) / run_len;
     const uint64_t total_units64 = (uint64_t)max_runs * n_waves32;
     const uint32_t total_units = total_units64 > 0xffffffffull ? 0xffffffffu : (uint32_t)total_units64;
@@ -265,7 +273,8 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
     auto run_of = [&](uint32_t u) __attribute__((always_inline)) {
         RunRef q;
         const uint32_t run = u / n_waves32;
-        q.g = u - run * n_waves32;
+        const uint32_t j = u - run * n_waves32;
+        q.g = wave_list ? wave_list[j] : j;
         q.pay_lo = wave_off[q.g] + 1u;
         q.n = wave_words[q.g];
         const uint32_t n_blocks = (q.n + BG::kWords - 1u) / BG::kWords;
@@ -370,7 +379,7 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
             if (!active) Qp = C - B0;
             uint32_t f = C - Qp;  // first code that starts in my segment
             uint32_t *const my_stage = stage + tid * kBlkLaneStride;
-            blk_parse<kBlkCount>(W, k, active, Qp, C - lim, cnt, sum, 0u, nullptr, my_stage);
+            blk_parse<kBlkCount, RESID>(W, k, active, Qp, C - lim, cnt, sum, 0u, nullptr, my_stage);
             if (!active) { cnt = 0; sum = 0; }
             uint32_t e = C - Qp;  // first code that starts behind it (or where the padding starts)
             BLK_STAMP(2);  // run-up + count (thread 0's wave)
@@ -384,7 +393,7 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
                     const bool changed = active && want != f;
                     if (!wg_any(changed)) break;  // (also: every read of s_e is done before the next write)
                     if (changed) { f = want; Qp = C - f; cnt = 0; sum = 0; }
-                    blk_parse<kBlkCount>(W, k, changed, Qp, C - lim, cnt, sum, 0u, nullptr, my_stage);
+                    blk_parse<kBlkCount, RESID>(W, k, changed, Qp, C - lim, cnt, sum, 0u, nullptr, my_stage);
                     if (changed) e = C - Qp;
                 }
             };
@@ -412,7 +421,7 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
                 const bool fix0 = tid == 0 && true_f0 != f;
                 if (wg_any(fix0)) {
                     if (fix0) { f = true_f0; Qp = C - f; cnt = 0; sum = 0; }
-                    blk_parse<kBlkCount>(W, k, fix0, Qp, C - lim, cnt, sum, 0u, nullptr, my_stage);
+                    blk_parse<kBlkCount, RESID>(W, k, fix0, Qp, C - lim, cnt, sum, 0u, nullptr, my_stage);
                     if (fix0) e = C - Qp;
                     settle();
                     // a one-block run has published its end already, and its successor has started from it: if that end
@@ -540,7 +549,7 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
 #pragma unroll
                 for (int i = 0; i < NR; ++i) rr[i] = my_stage[i];
                 blk_barrier();  // every lane holds its samples: the buffer may now be rewritten in output order
-                const uint32_t base16 = (acc_base + pre_s + incl_s - sum) & 0xffffu;  // the running sum in front of my first sample
+                const uint32_t base16 = RESID ? 0u : (acc_base + pre_s + incl_s - sum) & 0xffffu;  // the running sum in front of my first sample
                 const uint32_t slot0 = a0 + rel0, dump = 2u * BG::kStageWords - 1u;  // (the last halfword: beyond a0 + kOutCap)
 #pragma unroll
                 for (int i = 0; i < NR; ++i) {
@@ -561,7 +570,7 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
                     const uint32_t cmax = (rel0 >= R0 + BG::kOutCap) ? 0u : ((todo < R0 + BG::kOutCap - rel0) ? todo : R0 + BG::kOutCap - rel0);
                     // slot of sample c: a0 + rel0 + c - R0 (>= a0 for every c this pass decodes)
                     uint16_t *outp = obuf + (int32_t)(a0 + rel0 - R0);
-                    blk_parse<kBlkValue>(W, k, c < cmax, Qp, 0u, c, acc, cmax, outp);
+                    blk_parse<kBlkValue, RESID>(W, k, c < cmax, Qp, 0u, c, acc, cmax, outp);
                     blk_barrier();
                     copy_out(R0);
                     blk_barrier();
@@ -579,41 +588,97 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-static int blocks_nt(const Geom &G) {
+static int nt_for_len(uint32_t wave_len, uint32_t k) {
     // lanes per block: a waveform of about (k + 3.5) bits per sample should fill most of its last block
 #ifdef DRX_BLK_FORCE_NT
     return DRX_BLK_FORCE_NT;
 #endif
-    const uint64_t typ_words = ((uint64_t)G.u_wave_len * (2u * G.k + 7u)) >> 6;
+    const uint64_t typ_words = ((uint64_t)wave_len * (2u * k + 7u)) >> 6;
     return typ_words <= blk_words(64) ? 64 : (typ_words <= blk_words(128) ? 128 : 256);
 }
+static int blocks_nt(const Geom &G) { return G.uniform ? nt_for_len(G.u_wave_len, G.k) : (int)G.rag_blk_nt; }
 
-// Which batches take this decoder: uniform, delta filter, and cheaper here than a lane per waveform.  The two costs
-// (tools/len_sweep.py, profiles/r02_blocks_vs_lanes.txt, r02_len_sweep_*): a lane decodes ~17 samples per microsecond
+// blocks of `waves` waveforms of `wave_len` samples, weighted by what a block of theirs costs (1.7 for waveforms of one or two
+// blocks: they pay the ticket's dependent loads -- ticket, table entry, image -- per block: 36 us measured at 256 lanes, 10
+// chunks of 1166 x 12 000 and of 854 x 16 384)
+static double blocks_weighted(uint64_t waves, uint32_t wave_len, uint32_t k, int nt) {
+    const uint64_t typ_words = ((uint64_t)wave_len * (2u * k + 7u)) >> 6;
+    const uint64_t bpw = (typ_words + blk_words((uint32_t)nt) - 1u) / blk_words((uint32_t)nt);
+    return (double)(waves * bpw) * (bpw <= 2u ? 1.7 : 1.0);
+}
+static double blocks_us_of(double weighted_blocks, int nt) {
+    const double resident = nt == 256 ? 768.0 : (nt == 128 ? 1536.0 : 3072.0);
+    const double t_blk = nt == 256 ? 21.0 : (nt == 128 ? 28.0 : 41.0);
+    return (double)(uint64_t)((weighted_blocks + resident - 1.0) / resident) * t_blk;  // whole rounds of the resident grid
+}
+
+// Which batches take this decoder: the delta filter or a general filter the fast kernels take (its inverse then runs in place
+// behind this decoder, drx_iir.hip), waveforms of at least 2048 samples, and cheaper here than a lane per waveform.  The two
+// costs (tools/len_sweep.py, profiles/r02_blocks_vs_lanes.txt, r02_len_sweep_*): a lane decodes ~17 samples per microsecond
 // whatever else runs, so k_decode_lanes takes ~60 ns x WaveformLength per 98 304 waveforms; a block costs a workgroup 21 /
 // 28 / 41 us at 256 / 128 / 64 lanes, full or not, with 768 / 1536 / 3072 workgroups resident.  (Round 2's first rule, "at
 // most 24 576 waveforms", sent 25 chunks of 854 x 16 384 here: two blocks per waveform, the second a fifth full, 1.46 ms
-// where the lane kernel takes 0.98.)
+// where the lane kernel takes 0.98.)  Ragged batches: decided once from the host's chunk table, blocks_plan_ragged().
 bool blocks_batch(const Geom &G) {
-    if (!(G.uniform && G.n_taps == 0 && G.total_waves <= 98304u && G.u_wave_len >= 2048u)) return false;
+    if (G.n_taps != 0 && !G.fast_taps) return false;
+    if (!G.uniform) return G.rag_blocks != 0;
+    if (!(G.total_waves <= 98304u && G.u_wave_len >= 2048u)) return false;
     const int nt = blocks_nt(G);
     const uint64_t typ_words = ((uint64_t)G.u_wave_len * (2u * G.k + 7u)) >> 6;
     const uint64_t bpw = (typ_words + blk_words((uint32_t)nt) - 1u) / blk_words((uint32_t)nt);
-    const uint64_t resident = nt == 256 ? 768u : (nt == 128 ? 1536u : 3072u);
-    // (waveforms of one or two blocks pay the ticket's dependent loads -- ticket, table entry, image -- per block: 36 us measured
-    // at 256 lanes, 10 chunks of 1166 x 12 000 and of 854 x 16 384)
-    const double t_blk = (nt == 256 ? 21.0 : (nt == 128 ? 28.0 : 41.0)) * (bpw <= 2u ? 1.7 : 1.0);
-    const double blocks_us = (double)((G.total_waves * bpw + resident - 1u) / resident) * t_blk;
+    const double blocks_us = blocks_us_of((double)(G.total_waves * bpw), nt) * (bpw <= 2u ? 1.7 : 1.0);
     const double lanes_us = 0.06 * (double)G.u_wave_len * (double)((G.total_waves + 98303u) / 98304u);
     return blocks_us < lanes_us;
 }
 
+void blocks_plan_ragged(Geom &G, const ChunkDesc *d, uint32_t *list_out) {
+    G.rag_blocks = 0;
+    G.rag_blk_classes = 0;
+    uint32_t max_len = 0, min_len = 0xffffffffu;
+    for (uint64_t c = 0; c < G.n_chunks; ++c) {
+        max_len = d[c].wave_len > max_len ? d[c].wave_len : max_len;
+        min_len = d[c].wave_len < min_len ? d[c].wave_len : min_len;
+    }
+    if (G.total_waves > 98304u || min_len < 2048u) return;
+    const int nt = nt_for_len(max_len, G.k);
+    double wb = 0;
+    for (uint64_t c = 0; c < G.n_chunks; ++c) wb += blocks_weighted(d[c].n_waves, d[c].wave_len, G.k, nt);
+    // a lane takes 60 ns per sample: a lane-per-waveform launch lasts as long as its longest waveform, per 98 304 of them
+    const double lanes_us = 0.06 * (double)max_len * (double)((G.total_waves + 98303u) / 98304u);
+    if (!(blocks_us_of(wb, nt) < lanes_us)) return;
+    // look-back slots per waveform: enough for the longest one at 25 bits per sample, in blocks of the SMALLEST class's size
+    const uint64_t per = (max_payload_words(max_len) + blk_words(64u) - 1u) / blk_words(64u);
+    if (G.total_waves * per * 12u > (1ull << 30)) return;  // (one very long waveform among very many: the table would not pay)
+    G.rag_blocks = 1u;
+    G.rag_blk_nt = (uint32_t)nt;
+    G.rag_blk_slots = (uint32_t)(per ? per : 1u);
+    // classes by floor(log2 WaveformLength), longest first (the long classes start while the grid is empty)
+    uint32_t n_cls = 0, at = 0;
+    for (int b = 31; b >= 11; --b) {
+        uint32_t cnt = 0, cls_max = 0;
+        for (uint64_t c = 0; c < G.n_chunks; ++c) {
+            if ((31 - __builtin_clz(d[c].wave_len)) != b) continue;
+            for (uint32_t i = 0; i < d[c].n_waves; ++i) list_out[at + cnt++] = (uint32_t)(d[c].wave_base + i);
+            cls_max = d[c].wave_len > cls_max ? d[c].wave_len : cls_max;
+        }
+        if (!cnt) continue;
+        G.rag_blk_class_off[n_cls] = at;
+        G.rag_blk_class_len[n_cls] = cls_max;
+        at += cnt;
+        ++n_cls;
+    }
+    G.rag_blk_class_off[n_cls] = at;
+    G.rag_blk_classes = n_cls;
+}
+
 static uint32_t blocks_slots_per_wave(const Geom &G) {  // blocks of a waveform at 25 bits per sample
+    if (!G.uniform) return G.rag_blk_slots;
     const uint64_t per = (max_payload_words(G.u_wave_len) + blk_words(blocks_nt(G)) - 1u) / blk_words(blocks_nt(G));
     return (uint32_t)(per ? per : 1u);
 }
 
-// scratch: u32 info[4] | u32 fail[W] | u32 suspect[W] | u32 ticket[1] (+ pad to 16 bytes) | u32 ends[slots] | u64 state[slots] | prof
+constexpr uint32_t kBlkMaxClasses = 32;  // ragged batches: one launch per class of WaveformLengths floor(log2 L)
+// scratch: u32 info[32][4] | u32 fail[W] | u32 suspect[W] | u32 ticket[1] (+ pad to 16 bytes) | u32 ends[slots] | u64 state[slots] | prof
 struct BlkScratch {
     uint32_t *info, *fail, *suspect, *ticket, *ends;
     uint64_t *state;
@@ -622,12 +687,12 @@ struct BlkScratch {
 };
 static BlkScratch blocks_layout(const Geom &G, void *base) {
     const uint64_t W = G.total_waves, U = W * blocks_slots_per_wave(G);
-    uint64_t n32 = 4u + W + W + 1u;
+    uint64_t n32 = 4u * kBlkMaxClasses + W + W + 1u;  // info[class][4]: {most blocks of a waveform, tickets, the class's ticket word, -}
     n32 = (n32 + 3u) & ~3ull;
     BlkScratch L;
     uint32_t *p = reinterpret_cast<uint32_t *>(base);
     L.info = p;
-    L.fail = p + 4u;
+    L.fail = p + 4u * kBlkMaxClasses;
     L.suspect = L.fail + W;
     L.ticket = L.suspect + W;
     L.ends = p + n32;
@@ -642,29 +707,35 @@ uint64_t blocks_scratch_bytes(const Geom &G) { return blocks_batch(G) ? blocks_l
 
 hipError_t launch_decode_blocks(const Geom &G, const uint32_t *d_in, uint64_t in_words, const uint64_t *d_wave_off,
                                 const uint32_t *d_wave_words, void *d_blk, DevStatus *d_status, int16_t *d_out,
-                                const uint32_t **fail_out, const uint32_t **suspect_out, hipStream_t s) {
+                                const uint32_t **fail_out, const uint32_t **suspect_out, bool resid, hipStream_t s) {
     const BlkScratch L = blocks_layout(G, d_blk);
     hipError_t e = hipMemsetAsync(d_blk, 0, L.bytes, s);
     if (e != hipSuccess) return e;
-    const int nt = blocks_nt(G);
-    k_blk_max<<<1, 1024, 0, s>>>(G.total_waves, d_wave_words, blk_words((uint32_t)nt), L.info);
     // resident grid: 256 CUs x workgroups per CU (LDS: 51 KB at NT = 256, 26 KB at 128, 13 KB at 64), never more than there are units
     const uint32_t spw = blocks_slots_per_wave(G);
-    const uint64_t units = G.total_waves * spw;
-    // runs of several blocks only when two runs of one waveform are never in flight together (see the kernel)
-    const uint32_t run_len = G.total_waves >= 768u ? kBlkRun : 1u;
-    if (nt == 64) {
-        const unsigned grid = (unsigned)(units < 256u * 12u ? units : 256u * 12u);
-        k_decode_blocks<64><<<grid, 64, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, L.info, spw, run_len, L.state, L.ends, L.ticket,
-                                               L.fail, L.suspect, d_status, d_out, L.prof);
-    } else if (nt == 128) {
-        const unsigned grid = (unsigned)(units < 256u * 6u ? units : 256u * 6u);
-        k_decode_blocks<128><<<grid, 128, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, L.info, spw, run_len, L.state, L.ends, L.ticket,
-                                                 L.fail, L.suspect, d_status, d_out, L.prof);
+    auto launch_class = [&](uint32_t cls, const uint32_t *list, uint32_t n_waves, int nt) {
+        uint32_t *info = L.info + 4u * cls;
+        k_blk_max<<<1, 1024, 0, s>>>(n_waves, d_wave_words, blk_words((uint32_t)nt), info, list);
+        const uint64_t units = (uint64_t)n_waves * spw;
+        // runs of several blocks only when two runs of one waveform are never in flight together (see the kernel)
+        const uint32_t run_len = n_waves >= 768u ? kBlkRun : 1u;
+        auto go = [&](auto nt_tag, auto resid_tag, unsigned per_cu) {
+            constexpr int NT = decltype(nt_tag)::value;
+            constexpr bool RESID = decltype(resid_tag)::value;
+            const unsigned grid = (unsigned)(units < 256u * per_cu ? units : 256u * per_cu);
+            k_decode_blocks<NT, RESID><<<grid, NT, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, info, spw, run_len, L.state, L.ends,
+                                                           info + 2, L.fail, L.suspect, d_status, d_out, L.prof, list, n_waves);
+        };
+        if (nt == 64) { if (resid) go(std::integral_constant<int, 64>{}, std::true_type{}, 12u); else go(std::integral_constant<int, 64>{}, std::false_type{}, 12u); }
+        else if (nt == 128) { if (resid) go(std::integral_constant<int, 128>{}, std::true_type{}, 6u); else go(std::integral_constant<int, 128>{}, std::false_type{}, 6u); }
+        else { if (resid) go(std::integral_constant<int, 256>{}, std::true_type{}, 3u); else go(std::integral_constant<int, 256>{}, std::false_type{}, 3u); }
+    };
+    if (G.uniform) {
+        launch_class(0u, nullptr, (uint32_t)G.total_waves, blocks_nt(G));
     } else {
-        const unsigned grid = (unsigned)(units < 256u * 3u ? units : 256u * 3u);
-        k_decode_blocks<256><<<grid, 256, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, L.info, spw, run_len, L.state, L.ends, L.ticket,
-                                                 L.fail, L.suspect, d_status, d_out, L.prof);
+        for (uint32_t c = 0; c < G.rag_blk_classes; ++c)
+            launch_class(c, G.rag_blk_list + G.rag_blk_class_off[c], G.rag_blk_class_off[c + 1] - G.rag_blk_class_off[c],
+                         nt_for_len(G.rag_blk_class_len[c], G.k));
     }
 #ifdef DRX_BLK_STAMPS
     {

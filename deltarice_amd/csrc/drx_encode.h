@@ -70,7 +70,10 @@ __device__ __forceinline__ void packed_codes(const uint32_t x[4], uint32_t xprev
     }
 }
 
-constexpr uint32_t kEncCapWords = 2048;  // LDS words per waveform buffer (8 KB): 9.3 bits/sample at L = 7000
+#ifndef DRX_ENC_CAP_WORDS
+#define DRX_ENC_CAP_WORDS 2048
+#endif
+constexpr uint32_t kEncCapWords = DRX_ENC_CAP_WORDS;  // LDS words per waveform buffer (8 KB): 9.3 bits/sample at L = 7000
 
 // Loads this lane's 8 samples of the tile as 4 dwords; returns the number that exist.
 __device__ __forceinline__ int load8_dwords(const int16_t *__restrict__ x, uint32_t len, uint32_t t0, int lane,

@@ -53,6 +53,20 @@ struct Geom {
     const uint32_t *walk_short, *walk_long;
     uint32_t n_short, n_long, max_groups;
     uint64_t max_wave_len64;  // ragged batches: 64 x the longest WaveformLength (how far apart a wavefront's 64 lines can lie)
+    // ragged batches of few long waveforms: the block-parallel decoder takes them (decided when the plan is made, from the
+    // host's chunk table: drx_blocks.hip); lanes per block and look-back slots per waveform for the longest of them
+    uint32_t rag_blocks, rag_blk_nt, rag_blk_slots;
+    // ... launched once per class of WaveformLengths (floor(log2 L): the waveforms of a launch differ by less than 2x, so
+    // that run-major tickets over them are rarely empty): rag_blk_list = waveform indices class by class (device),
+    // class c = entries [rag_blk_class_off[c], rag_blk_class_off[c + 1]), its longest WaveformLength in rag_blk_class_len[c]
+    const uint32_t *rag_blk_list;
+    uint32_t rag_blk_classes;
+    uint32_t rag_blk_class_off[33], rag_blk_class_len[32];
+    // general prediction filter behind the block decoder (drx_iir.hip): tables, tiles and their look-back state
+    const uint32_t *iir_tab;
+    const uint64_t *iir_chunk_tile_base;  // ragged: first tile of every chunk, n_chunks + 1 entries
+    uint64_t iir_n_tiles;
+    uint64_t *iir_state;                  // uint64[iir_n_tiles + 1]
     // ragged batches that the segment encoder takes (some chunk has short or long waveforms): first unit (waveform x
     // segment slot) of every chunk, n_chunks + 1 entries, and their total
     const uint64_t *seg_unit_base;
@@ -108,16 +122,21 @@ struct SideStream {
     hipStream_t s;
     hipEvent_t fork, join;
 };
+// path_out (optional): which decoders the call used, DRX_PATH_* bits of include/deltarice_hip.h
 hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                          const uint64_t *d_chunk_word_off, int16_t *d_out, uint64_t *d_wave_off,
                          uint32_t *d_wave_words, uint64_t *d_granules, DevStatus *d_status, int impl,
-                         void *d_pw, void *d_blk, const SideStream *side, hipEvent_t *ev, hipStream_t s);
+                         void *d_pw, void *d_blk, const SideStream *side, hipEvent_t *ev, hipStream_t s, uint32_t *path_out = nullptr);
 // block-parallel decoder for batches of few waveforms (drx_blocks.hip): a workgroup per block of a waveform's stream
 bool blocks_batch(const Geom &G);
+// ragged plans: decides rag_blocks / rag_blk_nt / rag_blk_slots from the host's chunk table (call once, when the plan is made)
+// (list_out: the host copy of rag_blk_list, for the caller to upload)
+void blocks_plan_ragged(Geom &G, const ChunkDesc *host_chunks, uint32_t *list_out);
 uint64_t blocks_scratch_bytes(const Geom &G);
+// resid: leave the residuals (not their running sums) in d_out: a general prediction filter's inverse follows (launch_iir)
 hipError_t launch_decode_blocks(const Geom &G, const uint32_t *d_in, uint64_t in_words, const uint64_t *d_wave_off,
                                 const uint32_t *d_wave_words, void *d_blk, DevStatus *d_status, int16_t *d_out,
-                                const uint32_t **fail_out, const uint32_t **suspect_out, hipStream_t s);
+                                const uint32_t **fail_out, const uint32_t **suspect_out, bool resid, hipStream_t s);
 // single-pass encoder for short and long waveforms (drx_pieces.hip): a wavefront takes a PIECE, either a run of whole
 // short waveforms or one segment of a long one; the pieces of a chunk fill whole workgroups of kPcWaves wavefronts
 constexpr uint32_t kPcWaves = 8;
@@ -181,6 +200,14 @@ uint64_t pieces_scan_words(const Geom &G, uint64_t total_wgs);  // uint64 words 
 hipError_t launch_encode_pieces(const Geom &G, const int16_t *d_in, uint64_t in_samples, uint32_t *d_out, uint64_t out_cap,
                                 uint64_t *d_chunk_word_off, uint32_t *d_wave_words, uint64_t *d_scan, uint64_t total_wgs,
                                 DevStatus *d_status, hipEvent_t *ev, hipStream_t s);
+// in-place inverse of a general prediction filter over decoded residuals (drx_iir.hip): tiles of kIirThreads lanes x kIirRun
+// samples, decoupled look-back over kIirWin tiles per poll, tables of kIirTabWords uint32 per filter
+constexpr uint32_t kIirRun = 32, kIirThreads = 1024, kIirTile = kIirRun * kIirThreads, kIirWin = 128;
+constexpr uint32_t kIirTabWords = (7 + 64 + (kIirWin + 1)) * 9 + 4;
+void iir_tables(const uint32_t fast_nt[3], uint32_t t0neg, uint32_t *tab);
+uint64_t iir_tiles(const Geom &G, const ChunkDesc *host_chunks, uint64_t *chunk_tile_base);  // (chunk_tile_base: n_chunks + 1, ragged only)
+hipError_t launch_iir(const Geom &G, const uint64_t *d_chunk_tile_base, uint64_t n_tiles, const uint32_t *d_tab, uint64_t *d_state,
+                      const uint32_t *d_skip, DevStatus *d_status, int16_t *d_out, hipStream_t s);
 uint64_t par_walk_scratch_bytes(const Geom &G);
 uint32_t bw_walk_blocks_max(const Geom &G);
 constexpr uint32_t kWalkShortLenHost = 2048;  // keep equal to kWalkShortLen in drx_kernels.hip

@@ -310,9 +310,16 @@ __global__ __launch_bounds__(256) void k_encode_pack(Geom G, const int16_t *__re
 // (the packed tile code: drx_encode.h)
 
 constexpr int kEncWaves = 8;  // waveforms (wavefronts) per workgroup = per ticket
+#ifndef DRX_ENC_LB_WIN
+#define DRX_ENC_LB_WIN 2
+#endif
+constexpr int kLbWin = DRX_ENC_LB_WIN;  // look-back window of k_encode_fused in units of 64 entries
 
+#ifndef DRX_ENC_WAVES_PER_EU
+#define DRX_ENC_WAVES_PER_EU 1
+#endif
 template <bool GEN>
-__global__ __launch_bounds__(64 * kEncWaves) void k_encode_fused(Geom G, const int16_t *__restrict__ in,
+__global__ __launch_bounds__(64 * kEncWaves, DRX_ENC_WAVES_PER_EU) void k_encode_fused(Geom G, const int16_t *__restrict__ in,
                                                       uint32_t *__restrict__ out, uint64_t out_cap,
                                                       uint64_t *__restrict__ chunk_word_off,
                                                       uint32_t *__restrict__ wave_words,
@@ -466,20 +473,33 @@ __global__ __launch_bounds__(64 * kEncWaves) void k_encode_fused(Geom G, const i
             if (lane == 0) __hip_atomic_store(scan_state + T, kScanAgg | block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int64_t base = (int64_t)T - 1;
             uint32_t spins = 0;
+            // kLbWin x 64 entries per poll.  The frontier of known prefixes advances one window per hop (a hop = an
+            // agent-scope store becoming visible + an agent-scope load, 3-5 us under the encoder's own streaming loads), so
+            // the window bounds the rate of the whole kernel: 128 entries carried ~25 workgroups per microsecond, just what
+            // 1M waveforms in 6 ms need (round 3: without the look-back the kernel took 4.5 ms instead of 6.0)
             for (;;) {
-                // lane l looks at predecessors base-l (nearer) and base-64-l (farther)
-                const int64_t i0 = base - lane, i1 = base - 64 - lane;
-                uint64_t s0v = kScanPrefix, s1v = kScanPrefix;  // before the first workgroup: an empty prefix
-                if (i0 >= 0) s0v = __hip_atomic_load(scan_state + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (i1 >= 0) s1v = __hip_atomic_load(scan_state + i1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t st0 = (uint32_t)(s0v >> 62), st1 = (uint32_t)(s1v >> 62);
-                const uint64_t p0 = __ballot(st0 == 2u), z0 = __ballot(st0 == 0u);
-                const uint64_t p1 = __ballot(st1 == 2u), z1 = __ballot(st1 == 0u);
-                // position of the nearest prefix in the 128-entry window (0 = nearest predecessor)
-                const int fp = p0 ? __builtin_ctzll(p0) : (p1 ? 64 + __builtin_ctzll(p1) : 128);
-                const uint64_t near0 = fp >= 64 ? ~0ull : ((1ull << fp) - 1ull);
-                const uint64_t near1 = fp >= 128 ? ~0ull : (fp > 64 ? ((1ull << (fp - 64)) - 1ull) : 0ull);
-                if ((z0 & near0) | (z1 & near1)) {  // a nearer predecessor has not published yet
+                // lane l looks at predecessors base - 64 j - l, j = 0 (nearest) .. kLbWin - 1
+                uint64_t sv[kLbWin];
+                int fp = 64 * kLbWin;          // position of the nearest prefix in the window (0 = nearest predecessor)
+                bool hole = false;             // an entry nearer than that prefix has not been published yet
+#pragma unroll
+                for (int j = 0; j < kLbWin; ++j) {
+                    const int64_t i = base - 64 * j - lane;
+                    sv[j] = kScanPrefix;  // before the first workgroup: an empty prefix
+                    if (i >= 0) sv[j] = __hip_atomic_load(scan_state + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int j = 0; j < kLbWin; ++j) {
+                    const uint32_t stj = (uint32_t)(sv[j] >> 62);
+                    const uint64_t pj = __ballot(stj == 2u), zj = __ballot(stj == 0u);
+                    if (fp == 64 * kLbWin) {  // no prefix found in the nearer groups
+                        const int f = pj ? __builtin_ctzll(pj) : 64;
+                        const uint64_t nearer = f >= 64 ? ~0ull : ((1ull << f) - 1ull);
+                        hole = hole || (zj & nearer) != 0;
+                        if (pj) fp = 64 * j + f;
+                    }
+                }
+                if (hole) {  // a nearer predecessor has not published yet
                     __builtin_amdgcn_s_sleep(1);
                     if (++spins > (1u << 22)) {  // cannot happen with a zeroed scan_state; never hang the GPU
                         if (lane == 0) atomicOr(&st->err, kErrInternal);
@@ -487,15 +507,17 @@ __global__ __launch_bounds__(64 * kEncWaves) void k_encode_fused(Geom G, const i
                     }
                     continue;
                 }
-                const uint64_t c0 = (lane <= fp) ? (s0v & kScanValMask) : 0ull;
-                const uint64_t c1 = (64 + lane <= fp) ? (s1v & kScanValMask) : 0ull;
-                excl_blk += wave_sum_u64(c0 + c1);
-                if (fp < 128) break;
-                base -= 128;
+                uint64_t c = 0;
+#pragma unroll
+                for (int j = 0; j < kLbWin; ++j) c += (64 * j + lane <= fp) ? (sv[j] & kScanValMask) : 0ull;
+                excl_blk += wave_sum_u64(c);
+                if (fp < 64 * kLbWin) break;
+                base -= 64 * kLbWin;
             }
             if (lane == 0)
                 __hip_atomic_store(scan_state + T, kScanPrefix | (excl_blk + block_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (kAblate && (G.dbg & 1024u)) excl_blk = T * 2048ull * kEncWaves;  // ablation: look-back done, sparse placement all the same
         if (lane == 0) s_excl = excl_blk;
     }
     __syncthreads();
@@ -520,8 +542,19 @@ __global__ __launch_bounds__(64 * kEncWaves) void k_encode_fused(Geom G, const i
     }
     uint32_t *__restrict__ outp = out + pos + 1;
     if (fits) {
-        if (!(kAblate && (G.dbg & 64u)))
-            for (uint32_t i = lane; i < n; i += 64) outp[i] = buf[i];
+        if (!(kAblate && (G.dbg & 64u))) {
+            // 16 bytes per lane: 1 KB per store instruction instead of 256 bytes.  The waveform's place in the stream is
+            // only word aligned; unaligned vector stores are on for HSA queues, and a wavefront's 64 pieces are contiguous
+            // whatever their alignment (round 3: 22 store instructions per waveform became 6)
+            typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+            typedef u32x4s __attribute__((address_space(1), aligned(4))) g_u32x4_a4;
+            const uint32_t n4 = n & ~3u;
+            for (uint32_t i = 4u * (uint32_t)lane; i < n4; i += 256u) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(buf + i);
+                *(g_u32x4_a4 *)(outp + i) = (u32x4s){v.x, v.y, v.z, v.w};
+            }
+            if ((uint32_t)lane < n - n4) outp[n4 + (uint32_t)lane] = buf[n4 + (uint32_t)lane];
+        }
         return;
     }
 
@@ -1567,9 +1600,10 @@ __global__ __launch_bounds__(64) void k_walk_block_only(Geom G, const uint32_t *
 __global__ __launch_bounds__(64) void k_decode_simple(Geom G, const uint32_t *__restrict__ in,
                                                       const uint64_t *__restrict__ wave_off,
                                                       const uint32_t *__restrict__ wave_words, DevStatus *st,
-                                                      int16_t *__restrict__ out) {
+                                                      int16_t *__restrict__ out, const uint32_t *__restrict__ only) {
     const uint64_t g = (uint64_t)blockIdx.x * 64u + threadIdx.x;
     if (g >= G.total_waves) return;
+    if (only && !only[g]) return;  // (behind the block decoder with a general filter: the waveforms it flagged)
     const WaveRef r = locate(G, g);
     const uint32_t *s = in + wave_off[g] + 1;
     const uint32_t n = wave_words[g];
@@ -1647,7 +1681,7 @@ __global__ __launch_bounds__(kLongThreads) void k_decode_long(Geom G, const uint
                                                               const uint64_t *__restrict__ wave_off,
                                                               const uint32_t *__restrict__ wave_words, DevStatus *st,
                                                               int16_t *__restrict__ out, const uint32_t *__restrict__ fail,
-                                                              const uint32_t *__restrict__ suspect) {
+                                                              const uint32_t *__restrict__ suspect, uint32_t verdict_only) {
     constexpr uint32_t NT = kLongThreads;
     // [kLongRows - 2 - word of the segment][thread] (a lane's bank is its lane number whatever row it reads), rows
     // in REVERSE word order plus one unused row on top: with the bit position kept negated, Q = -pos, the row
@@ -1667,6 +1701,7 @@ __global__ __launch_bounds__(kLongThreads) void k_decode_long(Geom G, const uint
         if (suspect && suspect[g] && tid == 0) atomicOr(&st->err, kErrCorrupt);
         return;
     }
+    if (verdict_only) return;  // (general filters: flagged waveforms are decoded again by k_decode_simple, which judges them too)
     const WaveRef r = locate(G, g);
     const uint32_t *src = in + wave_off[g] + 1;
     const uint32_t n = wave_words[g];
@@ -2648,7 +2683,10 @@ static unsigned dec_lds_pad() {
 hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
                          const uint64_t *d_chunk_word_off, int16_t *d_out, uint64_t *d_wave_off,
                          uint32_t *d_wave_words, uint64_t *d_granules, DevStatus *d_status, int impl,
-                         void *d_pw, void *d_blk, const SideStream *side, hipEvent_t *ev, hipStream_t s) {
+                         void *d_pw, void *d_blk, const SideStream *side, hipEvent_t *ev, hipStream_t s, uint32_t *path_out) {
+    uint32_t path_dummy = 0;
+    uint32_t &path = path_out ? *path_out : path_dummy;
+    path = 0;
     if (G.total_waves == 0) return hipSuccess;
     const unsigned lpad = dec_lds_pad();
     mark(ev, 0, s);
@@ -2664,7 +2702,8 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
     if (tables_ready && impl == 8) impl = 7;
     // ragged: the group-major grid has max_groups tickets per chunk; not when most of them would be idle
     // few long waveforms (delta filter): a wavefront per waveform instead of a lane per waveform
-    const bool blocks_path = !gen && impl != 0 && !(G.dbg & (256u | 512u)) && d_blk && blocks_batch(G);
+    // (general filters the fast kernels take: the block decoder leaves residuals, the inverse filter runs in place behind it)
+    const bool blocks_path = impl != 0 && !(G.dbg & (256u | 512u)) && d_blk && blocks_batch(G) && (!gen || (G.iir_tab && G.iir_state));
     const bool long_path = !blocks_path && !gen && impl != 0 && !(G.dbg & 256u) && G.uniform && long_waveform_batch(G.total_waves, G.u_wave_len);
     // a handful of chunks of long-enough waveforms: the parallel walk, then a plain decode launch
     const bool par_walk = d_pw && !tables_ready && !(G.dbg & 2048u) && G.uniform && G.n_chunks <= kPwMaxChunks &&
@@ -2690,6 +2729,7 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
             groups = G.max_groups;
         }
         const unsigned nb = n_walk + (unsigned)(G.n_chunks * groups);
+        path |= 1u;  // DRX_PATH_LANES_FUSED
 #ifndef DRX_DEC_NW
 #define DRX_DEC_NW 1
 #endif
@@ -2713,6 +2753,7 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
     } else {
         // the lane-per-waveform launch outside the fused form (tables in wave_off / wave_words): `nb` wavefronts of view Gv
         auto launch_lanes = [&](const Geom &Gv, unsigned nb, int im, hipStream_t st_) {
+            path |= 2u;  // DRX_PATH_LANES
             if (im == 7 && gen)
                 k_decode_lanes<64, DRX_DEC_LW, DRX_DEC_T, 16, false, true, true><<<nb, 64, lpad, st_>>>(Gv, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, nullptr, nullptr, d_status, d_out);
             else if (im == 7)
@@ -2756,7 +2797,7 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
             // chunk-wide walk on the side stream, the rest here behind the block walk
             const int im_split = (impl == 0) ? 0 : ((impl == 5 || impl == 1) ? 1 : 7);
             const bool split = forked && G.rag_order && im_split != 0 && G.rag_groups_long && G.rag_groups_long < G.rag_groups &&
-                               !(G.dbg & 131072u);
+                               !(G.dbg & 131072u) && !blocks_path;
             if (split) {
                 Geom Gl = G;
                 Gl.rag_groups = G.rag_groups_long;
@@ -2832,15 +2873,22 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
             // a workgroup per block of every waveform (drx_blocks.hip); waveforms it flags are decoded again, one
             // workgroup each, by the kernel that also judges them
             const uint32_t *fail = nullptr, *suspect = nullptr;
-            hipError_t e = launch_decode_blocks(G, d_in, in_words, d_wave_off, d_wave_words, d_blk, d_status, d_out, &fail, &suspect, s);
+            path |= 4u | (gen ? 32u : 0u);  // DRX_PATH_BLOCKS (| DRX_PATH_IIR)
+            hipError_t e = launch_decode_blocks(G, d_in, in_words, d_wave_off, d_wave_words, d_blk, d_status, d_out, &fail, &suspect, gen, s);
             if (e != hipSuccess) return e;
-            k_decode_long<<<(unsigned)G.total_waves, kLongThreads, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_status, d_out, fail, suspect);
+            k_decode_long<<<(unsigned)G.total_waves, kLongThreads, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_status, d_out, fail, suspect, gen ? 1u : 0u);
+            if (gen) {
+                // residuals -> samples, in place; then the waveforms the block decoder flagged, serially (a slope-1 ramp)
+                if ((e = launch_iir(G, G.iir_chunk_tile_base, G.iir_n_tiles, G.iir_tab, G.iir_state, fail, d_status, d_out, s)) != hipSuccess) return e;
+                k_decode_simple<<<nb_plain, 64, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_status, d_out, fail);
+            }
             mark(ev, 2, s);
             mark(ev, 3, s);
             return hipGetLastError();
         }
         if (long_path) {  // (flag 512, or a long-waveform batch the block decoder does not take: one workgroup per waveform)
-            k_decode_long<<<(unsigned)G.total_waves, kLongThreads, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_status, d_out, nullptr, nullptr);
+            path |= 8u;  // DRX_PATH_LONG
+            k_decode_long<<<(unsigned)G.total_waves, kLongThreads, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_status, d_out, nullptr, nullptr, 0u);
             mark(ev, 2, s);
             mark(ev, 3, s);
             return hipGetLastError();
@@ -2848,8 +2896,9 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
         if (impl == 5) impl = 1;  // (a batch that cannot take the in-launch walk)
         if (impl == 8) impl = 7;
         const unsigned nb = (!G.uniform && G.rag_order) ? G.rag_groups : nb_plain;  // (groups per chunk round up)
+        if (impl == 0) path |= 16u;  // DRX_PATH_SIMPLE
         if (impl == 0)
-            k_decode_simple<<<nb_plain, 64, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_status, d_out);
+            k_decode_simple<<<nb_plain, 64, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_status, d_out, nullptr);
         else
             launch_lanes(G, nb, impl, s);
     }

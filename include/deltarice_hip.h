@@ -127,6 +127,14 @@ drx_status drx_plan_finish(drx_plan *plan, uint64_t *total_words);
  * per-waveform payload word counts n_i and header word offsets.  For tests/tools. */
 const uint32_t *drx_plan_wave_words(const drx_plan *plan);
 const uint64_t *drx_plan_wave_word_off(const drx_plan *plan);
+/* Which decoders the plan's last drx_decode used (for tests and tools): the batch's geometry and filter choose among them. */
+#define DRX_PATH_LANES_FUSED 1u /* a lane per waveform, header walk inside the launch */
+#define DRX_PATH_LANES 2u       /* a lane per waveform behind a separate walk */
+#define DRX_PATH_BLOCKS 4u      /* a workgroup per block of a waveform's stream (few long waveforms) */
+#define DRX_PATH_LONG 8u        /* a workgroup per waveform */
+#define DRX_PATH_SIMPLE 16u     /* the simple kernel (filters the fast kernels do not take) */
+#define DRX_PATH_IIR 32u        /* residuals first, then the general filter's inverse in place, parallel inside a waveform */
+uint32_t drx_plan_last_decode_path(const drx_plan *plan);
 /* Copies n_i of every waveform to host memory (waits for the stream). */
 drx_status drx_plan_read_wave_words(drx_plan *plan, uint32_t *host_out);
 

@@ -7,6 +7,10 @@
              (src/deltaRice.c:249-258)
   nedm       chunks of 32 x 81 920   (the reference's nEDM@SNS shape, docs/Performance.md:27), 256 chunks
   noptrex    chunks of 32 x 500 000  (NOPTREX, docs/Performance.md:38), 64 chunks
+  noptrex_fir4   the same with the prediction filter the reference recommends for NOPTREX, taps [1,-1,1,-1] (docs/Optimization.md:21)
+  nedm_fir4      the nEDM shape with that filter
+  raglong    a ragged batch of few long waveforms: 48 chunks, WaveformLength in {81 920, 500 000, 250 000, whole chunk}
+  raglong_fir4   the same with taps [1,-1,1,-1]
   nab1       ONE chunk of 2000 x 7000 (what one H5Z call sees, docs/Performance.md:16)
   small20    ONE chunk of 20 x 7000  (README.md:75-82, BASELINE config #1's chunk)
   small100   ONE chunk of 100 x 7000
@@ -26,8 +30,20 @@ sys.path.insert(0, ROOT)
 import deltarice_amd as dr  # noqa: E402
 
 
+FIR4 = (1, -1, 1, -1)
+
+
 def geometry(name):
-    """-> (chunk_samples list, wave_len list, uniform opts or None)"""
+    """-> (chunk_samples list, wave_len list)"""
+    if name.endswith("_fir4"):
+        name = name[:-5]
+    if name == "raglong":
+        Ls, Ns = [], []
+        for _ in range(12):
+            for L, W in ((81920, 32), (500000, 8), (250000, 16), (0, 1)):
+                Ls.append(L)
+                Ns.append(L * W if L else 3_000_000)
+        return Ns, Ls
     if name == "headline":
         return [2000 * 7000] * 500, [7000] * 500
     if name == "config5":
@@ -59,6 +75,7 @@ def main():
     ap.add_argument("--m", type=int, default=8)
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--debug-flags", type=int, default=0)
+    ap.add_argument("--white", action="store_true", help="_fir4 workloads: white noise as it is (the filter then hurts)")
     a = ap.parse_args()
     Ns, Ls = geometry(a.name)
     ctx = dr.Context(0)
@@ -73,12 +90,28 @@ def main():
         n = min(slab, total - s0)
         x[s0:s0 + n] = (torch.randn(n, device=ctx.device, generator=g) * 10).to(torch.int16)
     uniform = len(set(Ns)) == 1 and len(set(Ls)) == 1
+    taps = FIR4 if a.name.endswith("_fir4") else None
     if uniform:
-        plan = ctx.plan_uniform(len(Ns), Ns[0], (a.m, Ls[0]) if Ls[0] else (a.m,))
+        opts = (a.m, Ls[0] if Ls[0] else Ns[0]) if (Ls[0] or taps) else (a.m,)
+        if taps:
+            opts = opts + (len(taps),) + tuple(t & 0xFFFFFFFF for t in taps)
+        plan = ctx.plan_uniform(len(Ns), Ns[0], opts)
     else:
-        plan = ctx.plan(Ns, Ls, a.m)
+        plan = ctx.plan(Ns, Ls, a.m, taps=taps)
     words = torch.empty(plan.max_encoded_words, dtype=torch.int32, device=ctx.device)
     off = torch.empty(len(Ns) + 1, dtype=torch.int64, device=ctx.device)
+    if taps and not a.white:
+        # data the filter suits: samples whose RESIDUALS under the filter are the Gaussian noise above (white noise through
+        # [1,-1,1,-1] doubles its sigma and escapes 11 % of the samples at m = 8, which is not what the filter is chosen for).
+        # Built with the codec itself: the residuals coded with the identity filter are the stream the filter's inverse decodes.
+        if uniform:
+            ident = ctx.plan_uniform(len(Ns), Ns[0], (a.m, Ls[0] if Ls[0] else Ns[0], 1, 1))
+        else:
+            ident = ctx.plan(Ns, Ls, a.m, taps=(1,))
+        ident.encode_async(x, words, off)
+        n0 = ident.finish()
+        x = plan.decode_async(words, off, torch.empty_like(x), in_words=n0)
+        plan.finish()
     y = torch.empty_like(x)
     torch.cuda.synchronize()
     te, td = [], []
@@ -100,7 +133,7 @@ def main():
     ratio = nwords * 4 / raw
     algo = raw * (1 + ratio)
     print(json.dumps({
-        "workload": a.name, "chunks": len(Ns), "samples": total, "m": a.m, "ratio": ratio,
+        "workload": a.name, "chunks": len(Ns), "samples": total, "m": a.m, "ratio": ratio, "decode_path": plan.last_decode_path(),
         "encode_ms": {"prepare": float(te[0]), "scan": float(te[1]), "pack": float(te[2]), "total": float(te[3])},
         "decode_ms": {"walk": float(td[0]), "decode": float(td[1]), "total": float(td[3])},
         "encode_GBps_int16": raw / te[3] / 1e6, "decode_GBps_int16": raw / td[3] / 1e6,

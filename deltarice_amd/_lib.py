@@ -55,6 +55,7 @@ SIGNATURES = {
     "drx_plan_read_wave_words": (C.c_int, [_vp, C.POINTER(_u32)]),
     "drx_encode": (C.c_int, [_vp, _vp, _vp, _u64, _vp]),
     "drx_decode": (C.c_int, [_vp, _vp, _u64, _vp, _vp]),
+    "drx_decode_with_wave_words": (C.c_int, [_vp, _vp, _u64, _vp, _vp, _vp]),
     "drx_estimate_words": (C.c_int, [_vp, _vp, C.POINTER(_u64)]),
     "drx_plan_last_timings": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "drx_plan_finish": (C.c_int, [_vp, C.POINTER(_u64)]),

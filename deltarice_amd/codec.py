@@ -189,6 +189,25 @@ class Plan:
                                                 out.data_ptr()))
         return out
 
+    def decode_with_wave_words(self, words: torch.Tensor, chunk_word_off: torch.Tensor, wave_words: torch.Tensor,
+                               out: Optional[torch.Tensor] = None, in_words: Optional[int] = None) -> torch.Tensor:
+        """Decode with the encoder's n_i table as a side-band (int32 tensor [total_waves] on the device): no header walk.
+        Launch only; finish() raises DRX_ERR_CORRUPT if the table does not belong to the stream."""
+        self._dev_check(words, torch.int32, 1, "words")
+        self._dev_check(chunk_word_off, torch.int64, self.n_chunks + 1, "chunk_word_off")
+        self._dev_check(wave_words, torch.int32, self.total_waves, "wave_words")
+        if out is None:
+            out = torch.empty(self.total_samples, dtype=torch.int16, device=self.ctx.device)
+        self._dev_check(out, torch.int16, self.total_samples, "out")
+        n = words.numel() if in_words is None else int(in_words)
+        self.ctx._check(self.ctx.lib.drx_decode_with_wave_words(self._h, words.data_ptr(), n, chunk_word_off.data_ptr(),
+                                                                wave_words.data_ptr(), out.data_ptr()))
+        return out
+
+    def wave_words_device(self) -> torch.Tensor:
+        """A device copy of n_i of every waveform from the last encode/decode (the side-band of decode_with_wave_words)."""
+        return torch.from_numpy(self.wave_words().view(np.int32)).to(self.ctx.device)
+
     def decode(self, enc: EncodedBatch, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         cur = torch.cuda.current_stream(self.ctx.device)
         self.ctx.stream.wait_stream(cur)

@@ -605,12 +605,18 @@ drx_status drx_encode(drx_plan *p, const int16_t *d_in, uint32_t *d_out, uint64_
 }
 
 static drx_status decode_launch(drx_plan *p, const uint32_t *d_in, uint64_t in_words,
-                                const uint64_t *d_chunk_word_off, int16_t *d_out, bool tables_ready) {
+                                const uint64_t *d_chunk_word_off, int16_t *d_out, bool tables_ready,
+                                const uint32_t *d_sideband = nullptr) {
     if (!p || !d_in || !d_chunk_word_off || !d_out) return DRX_ERR_ARG;
     drx_ctx *ctx = p->ctx;
     DRX_ON_DEVICE(ctx);
     DRX_HIP(ctx, hipMemsetAsync(p->d_status, 0, sizeof(DevStatus), ctx->stream));
     p->G.dbg = ctx->debug_flags;
+    if (d_sideband) {  // header positions from the caller's n_i table, checked against the stream (k_sideband_tables)
+        DRX_HIP(ctx, launch_sideband_tables(p->G, d_in, in_words, d_chunk_word_off, d_sideband, p->d_wave_off, p->d_wave_words,
+                                            p->d_status, ctx->stream));
+        tables_ready = true;
+    }
     // (d_pw / d_blk were allocated with the plan; a plan whose filter was set to general taps afterwards simply does
     // not take those paths)
     DRX_HIP(ctx, launch_decode(p->G, d_in, in_words, d_chunk_word_off, d_out, p->d_wave_off,
@@ -625,6 +631,13 @@ static drx_status decode_launch(drx_plan *p, const uint32_t *d_in, uint64_t in_w
 drx_status drx_decode(drx_plan *p, const uint32_t *d_in, uint64_t in_words,
                       const uint64_t *d_chunk_word_off, int16_t *d_out) {
     return decode_launch(p, d_in, in_words, d_chunk_word_off, d_out, false);
+}
+
+drx_status drx_decode_with_wave_words(drx_plan *p, const uint32_t *d_in, uint64_t in_words, const uint64_t *d_chunk_word_off,
+                                      const uint32_t *d_wave_words, int16_t *d_out) {
+    if (!d_wave_words) return DRX_ERR_ARG;
+    if (p && d_wave_words == p->d_wave_words) return fail(p->ctx, DRX_ERR_ARG, "the side-band table must not be the plan's own (copy it first)");
+    return decode_launch(p, d_in, in_words, d_chunk_word_off, d_out, false, d_wave_words);
 }
 
 // Header chain of ONE encoded chunk in host memory (src/deltaRice.c:320-325), with the validation the device

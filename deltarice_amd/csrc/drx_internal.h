@@ -100,6 +100,8 @@ hipError_t launch_encode(const Geom &G, const int16_t *d_in, uint32_t *d_out, ui
                          uint64_t *d_chunk_word_off, uint32_t *d_wave_words, uint32_t *d_wave_rel,
                          uint64_t *d_chunk_words, DevStatus *d_status, hipEvent_t *ev, hipStream_t s);
 
+hipError_t launch_sideband_tables(const Geom &G, const uint32_t *d_in, uint64_t in_words, const uint64_t *d_chunk_word_off,
+                                  const uint32_t *d_n, uint64_t *d_wave_off, uint32_t *d_wave_words, DevStatus *d_status, hipStream_t s);
 hipError_t launch_estimate_words(const Geom &G, const int16_t *d_in, unsigned long long *d_words16, hipStream_t s);
 
 hipError_t launch_encode_fused(const Geom &G, const int16_t *d_in, uint32_t *d_out, uint64_t out_cap,

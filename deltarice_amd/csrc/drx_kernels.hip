@@ -175,6 +175,50 @@ __global__ __launch_bounds__(256) void k_chunk_scan(Geom G, const uint32_t *__re
     if (threadIdx.x == 0) chunk_words[c] = run;
 }
 
+// Side-band decode (drx_decode_with_wave_words): the caller hands over the n_i table an encode left behind (SURVEY section 7:
+// "reuse its offset table as a side-band"), so no header chain is walked.  Per chunk: header positions by a prefix sum over
+// 1 + n_i, each checked against the stream itself (the word at that position must BE n_i, n_i within the bounds of its
+// waveform, the chain must end exactly at the chunk's end, the chunk header must be the sample count) -- a table that does
+// not belong to the stream is DRX_ERR_CORRUPT, never a wild read.
+__global__ __launch_bounds__(256) void k_sideband_tables(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
+                                                         const uint64_t *__restrict__ chunk_word_off,
+                                                         const uint32_t *__restrict__ n_in, uint64_t *__restrict__ wave_off,
+                                                         uint32_t *__restrict__ wave_words, DevStatus *st) {
+    __shared__ uint32_t wsum[4];
+    const uint64_t c = blockIdx.x;
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    uint64_t base;
+    uint32_t W, L, N;
+    if (G.uniform) { base = c * G.u_n_waves; W = G.u_n_waves; L = G.u_wave_len; N = G.u_n_samples; }
+    else { const ChunkDesc d = G.chunks[c]; base = d.wave_base; W = d.n_waves; L = d.wave_len; N = d.n_samples; }
+    const uint64_t off0 = chunk_word_off[c], off1 = chunk_word_off[c + 1];
+    bool bad = off1 > in_words || off0 >= off1;
+    uint64_t run = 1;  // the chunk header word
+    for (uint32_t i0 = 0; i0 < W; i0 += 256) {
+        const uint32_t i = i0 + threadIdx.x;
+        const uint32_t n = (i < W) ? n_in[base + i] : 0u;
+        const uint32_t v = (i < W) ? n + 1u : 0u;
+        const uint32_t inc = wave_incl_scan_u32(v, lane);
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { before += (w < wv) ? wsum[w] : 0u; all += wsum[w]; }
+        if (i < W) {
+            const uint64_t at = off0 + run + before + inc - v;
+            const uint32_t len = (i + 1u == W) ? N - i * L : L;
+            if (n > max_payload_words(len) || n < min_payload_words(len, G.k) || at + 1u + n > off1 || bad) bad = true;
+            else if (in[at] != n) bad = true;
+            wave_off[base + i] = bad ? off0 : at;  // (a rejected table is never dereferenced: the launch behind this is skipped on error)
+            wave_words[base + i] = bad ? 0u : n;
+        }
+        run += all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && !bad && (off0 + run != off1 || in[off0] != N)) bad = true;
+    if (bad) atomicOr(&st->err, kErrCorrupt);
+}
+
 // Exclusive prefix over chunk totals -> chunk_word_off[0..n_chunks]; one workgroup.
 __global__ __launch_bounds__(1024) void k_chunk_offsets(uint64_t n_chunks, const uint64_t *__restrict__ chunk_words,
                                                         uint64_t *__restrict__ chunk_word_off,
@@ -2529,6 +2573,13 @@ static inline unsigned blocks_for(uint64_t items, unsigned per_block) {
 
 static inline void mark(hipEvent_t *ev, int i, hipStream_t s) {
     if (ev) (void)hipEventRecord(ev[i], s);
+}
+
+hipError_t launch_sideband_tables(const Geom &G, const uint32_t *d_in, uint64_t in_words, const uint64_t *d_chunk_word_off,
+                                  const uint32_t *d_n, uint64_t *d_wave_off, uint32_t *d_wave_words, DevStatus *d_status, hipStream_t s) {
+    if (G.total_waves == 0) return hipSuccess;
+    k_sideband_tables<<<(unsigned)G.n_chunks, 256, 0, s>>>(G, d_in, in_words, d_chunk_word_off, d_n, d_wave_off, d_wave_words, d_status);
+    return hipGetLastError();
 }
 
 hipError_t launch_estimate_words(const Geom &G, const int16_t *d_in, unsigned long long *d_words16, hipStream_t s) {

@@ -114,6 +114,15 @@ drx_status drx_encode(drx_plan *plan, const int16_t *d_in, uint32_t *d_out, uint
 drx_status drx_decode(drx_plan *plan, const uint32_t *d_in, uint64_t in_words,
                       const uint64_t *d_chunk_word_off, int16_t *d_out);
 
+/* Decode with a side-band: d_wave_words = the n_i of every waveform (uint32[total_waves], e.g. a copy of what
+ * drx_plan_wave_words() shows after the drx_encode that produced d_in).  The reference's format has no index, so drx_decode
+ * must find every waveform's header by walking or searching the stream (src/deltaRice.c:320-325); a device-resident pipeline
+ * that still has the encoder's table can hand it back and skip that.  NOT part of the HDF5 drop-in surface (a file holds no
+ * such table) and never used by bench.py.  The table is checked against the stream (every header word must equal its n_i,
+ * the chain must end at the chunk's end): a table that does not belong to the stream is DRX_ERR_CORRUPT. */
+drx_status drx_decode_with_wave_words(drx_plan *plan, const uint32_t *d_in, uint64_t in_words,
+                                      const uint64_t *d_chunk_word_off, const uint32_t *d_wave_words, int16_t *d_out);
+
 /* RiceParameter optimiser (docs/Optimization.md:5-19 of the reference describes one, the tree does not
  * contain it): exact number of uint32 words drx_encode would emit for this batch with RiceParameter
  * 2^k, for every k = 0..15 (host array of 16), in one pass over the samples.  Synchronous. */

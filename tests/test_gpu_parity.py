@@ -763,3 +763,42 @@ def test_corrupt_headers_through_the_parallel_walks(ctx, O):
         bad[int(ref_off[1])] += 1  # the chunk's sample count
         with pytest.raises(dr.DeltaRiceError):
             plan.decode(dr.EncodedBatch(dev(ctx, bad.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), bad.size))
+
+
+def test_decode_with_the_encoders_table_as_a_side_band(ctx, O):
+    """drx_decode_with_wave_words: the n_i table an encode left behind replaces the header walk; the table
+    is checked against the stream, a wrong one is DRX_ERR_CORRUPT and never a wild read.  Uniform, ragged (config 5's
+    lengths), a general filter, few long waveforms (block decoder behind the side-band)."""
+    import deltarice_amd as dr
+    rng = np.random.default_rng(91)
+    cases = [("uniform", [7000 * 40] * 6, [7000] * 6, None), ("ragged", [512 * 40, 2048 * 9 + 17, 7000 * 3, 16384 * 2, 4321], [512, 2048, 7000, 16384, 0], None),
+             ("fir", [3000 * 5 + 11] * 3, [3000] * 3, (1, -1, 1, -1)), ("long", [60000 * 3] * 2, [60000] * 2, None)]
+    for name, Ns, Ls, taps in cases:
+        x = rng.normal(0, 10, sum(Ns)).astype(np.int16)
+        if name == "ragged":
+            plan = ctx.plan(Ns, Ls, 8)
+        else:
+            opts = (8, Ls[0]) + ((len(taps),) + tuple(t & 0xFFFFFFFF for t in taps) if taps else ())
+            plan = ctx.plan_uniform(len(Ns), Ns[0], opts)
+        enc = plan.encode(dev(ctx, x))
+        table = plan.wave_words_device()
+        y = plan.decode_with_wave_words(enc.words, enc.chunk_word_off, table, in_words=enc.total_words)
+        plan.finish()
+        assert np.array_equal(y.cpu().numpy(), x), name
+        assert np.array_equal(plan.decode(enc).cpu().numpy(), x)
+        # a table that does not belong to the stream
+        for damage in ("plus1", "swap", "zero"):
+            t = table.clone()
+            if damage == "plus1":
+                t[len(t) // 2] += 1
+            elif damage == "swap" and len(t) > 3 and int(t[0]) != int(t[1]):
+                t[0], t[1] = t[1].clone(), t[0].clone()
+            elif damage == "zero":
+                t[-1] = 0
+            else:
+                continue
+            plan.decode_with_wave_words(enc.words, enc.chunk_word_off, t, in_words=enc.total_words)
+            with pytest.raises(dr.DeltaRiceError) as ei:
+                plan.finish()
+            assert ei.value.status == 4, (name, damage)
+        assert np.array_equal(plan.decode(enc).cpu().numpy(), x)  # the plan is still usable

@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--m", type=int, default=8)
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--debug-flags", type=int, default=0)
+    ap.add_argument("--sideband", action="store_true", help="decode with the encoder's n_i table as a side-band (drx_decode_with_wave_words)")
     ap.add_argument("--white", action="store_true", help="_fir4 workloads: white noise as it is (the filter then hurts)")
     a = ap.parse_args()
     Ns, Ls = geometry(a.name)
@@ -121,7 +122,11 @@ def main():
         t = plan.last_timings()
         if i:
             te.append(t)
-        plan.decode_async(words, off, y, in_words=nwords)
+        if a.sideband:
+            table = plan.wave_words_device()
+            plan.decode_with_wave_words(words, off, table, y, in_words=nwords)
+        else:
+            plan.decode_async(words, off, y, in_words=nwords)
         plan.finish()
         t = plan.last_timings()
         if i:

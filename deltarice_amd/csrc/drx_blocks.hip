@@ -462,6 +462,16 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
                     const int64_t first = (int64_t)sidx - (int64_t)blk;  // block 0 of this waveform
                     int64_t base = (int64_t)sidx - 1;
                     uint32_t spins = 0;
+#ifndef DRX_BLK_NO_GATE
+                    // the nearest predecessor alone first (one 8-byte load per poll, not a window from every waiting workgroup)
+                    for (;;) {
+                        uint64_t v = 0;
+                        if (lane == 0) v = __hip_atomic_load(state + base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 62)) != 0) break;
+                        __builtin_amdgcn_s_sleep(4);
+                        if (++spins > (1u << 22)) break;  // (the window loop below reports it)
+                    }
+#endif
                     for (;;) {
                         // lane l looks at predecessors base - l (nearer) and base - 64 - l (farther)
                         const int64_t i0 = base - lane, i1 = base - 64 - lane;

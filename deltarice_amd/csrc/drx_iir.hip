@@ -184,6 +184,13 @@ __global__ __launch_bounds__(kIirThreads) void k_iir_tiles(Geom G, const uint64_
             for (int i = 0; i < 9; ++i) R.m[i] = (i % 4 == 0) ? 1u : 0u;
             const M3 Pwin = load_m3(tab + kIirPTP + 9 * kIirWin);
             uint32_t spins = 0;
+            for (;;) {  // the nearest predecessor alone first: one 8-byte load per poll (see k_encode_fused)
+                uint64_t v = 0;
+                if (lane == 0) v = __hip_atomic_load(state + base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 62)) != 0) break;
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > (1u << 22)) break;  // (the window loop below reports it)
+            }
             for (;;) {
                 // lane l looks at predecessors base - l (nearer) and base - 64 - l (farther); in front of tile 0 the state is zero
                 const int64_t j0 = base - lane, j1 = base - 64 - lane;

@@ -357,6 +357,9 @@ constexpr int kEncWaves = 8;  // waveforms (wavefronts) per workgroup = per tick
 #ifndef DRX_ENC_LB_WIN
 #define DRX_ENC_LB_WIN 2
 #endif
+#ifndef DRX_ENC_GATE_SLEEP
+#define DRX_ENC_GATE_SLEEP 8
+#endif
 constexpr int kLbWin = DRX_ENC_LB_WIN;  // look-back window of k_encode_fused in units of 64 entries
 
 #ifndef DRX_ENC_WAVES_PER_EU
@@ -517,6 +520,19 @@ __global__ __launch_bounds__(64 * kEncWaves, DRX_ENC_WAVES_PER_EU) void k_encode
             if (lane == 0) __hip_atomic_store(scan_state + T, kScanAgg | block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int64_t base = (int64_t)T - 1;
             uint32_t spins = 0;
+#ifndef DRX_ENC_NO_GATE
+            // Wait for the NEAREST predecessor alone first: one 8-byte load per poll instead of a whole window from every
+            // waiting workgroup.  Workgroups finish roughly in ticket order, so when T - 1 has published, the window behind it
+            // has too; and ~500 workgroups polling 128 entries each were a fabric load of their own beside the encoder's
+            // streaming reads (agent-scope loads are served by the memory side, not by L2).
+            for (;;) {
+                uint64_t v = 0;
+                if (lane == 0) v = __hip_atomic_load(scan_state + base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 62)) != 0) break;
+                __builtin_amdgcn_s_sleep(DRX_ENC_GATE_SLEEP);
+                if (++spins > (1u << 22)) break;  // (the window loop below reports it)
+            }
+#endif
             // kLbWin x 64 entries per poll.  The frontier of known prefixes advances one window per hop (a hop = an
             // agent-scope store becoming visible + an agent-scope load, 3-5 us under the encoder's own streaming loads), so
             // the window bounds the rate of the whole kernel: 128 entries carried ~25 workgroups per microsecond, just what

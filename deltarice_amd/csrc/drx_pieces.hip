@@ -89,6 +89,15 @@ __device__ __forceinline__ uint64_t lookback_sum(const uint64_t *state, int64_t 
     uint64_t sum = 0;
     int64_t base = idx - 1;
     uint32_t spins = 0;
+    // the nearest predecessor alone first, one 8-byte load per poll: hundreds of waiting workgroups polling whole windows
+    // were a fabric load of their own (k_encode_fused: 5.86 -> 5.43 ms, profiles/r03_notes.md)
+    while (base >= first) {
+        uint64_t v = 0;
+        if (lane == 0) v = __hip_atomic_load(state + base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 62)) != 0) break;
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1u << 22)) break;  // (the window loop below reports it)
+    }
     for (;;) {
         const int64_t i0 = base - lane, i1 = base - 64 - lane;
         uint64_t s0v = kScanPrefix, s1v = kScanPrefix;  // in front of `first`: an empty prefix

@@ -2077,22 +2077,6 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 1 : (NW == 4 ? 2 : 3)) void k_de
             }
         }
         uint32_t spins = 0;
-        {   // A chain releases a chunk's waveforms in order: wait for the LAST of this wavefront's with one lane (one 8-byte
-            // load per poll) before all 64 lanes fetch theirs -- at the start of a launch 1500 wavefronts wait for the
-            // walkers, and 64 agent-scope loads per poll from each of them compete with the very chains they wait for
-            const uint64_t ball = __ballot(active);
-            if (ball) {
-                const int last = 63 - __builtin_clzll(ball);
-                const uint64_t g_last = (uint64_t)__shfl((int)(uint32_t)g, last) | ((uint64_t)__shfl((int)(uint32_t)(g >> 32), last) << 32);
-                for (;;) {
-                    uint64_t v = 0;
-                    if (lane == 0) v = __hip_atomic_load(granules + g_last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) & (int)(uint32_t)(kGranValid >> 32)) break;
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1u << 24)) break;  // (the loop below reports it)
-                }
-            }
-        }
         for (;;) {  // wait for this wave's granules; the walker that writes them holds a lower ticket
             if (active && !(gr & kGranValid))
                 gr = __hip_atomic_load(granules + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

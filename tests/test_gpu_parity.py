@@ -802,3 +802,40 @@ def test_decode_with_the_encoders_table_as_a_side_band(ctx, O):
                 plan.finish()
             assert ei.value.status == 4, (name, damage)
         assert np.array_equal(plan.decode(enc).cpu().numpy(), x)  # the plan is still usable
+
+
+def test_large_chunks_through_the_host_path(ctx, O):
+    """One large chunk through host memory (what the H5Z callback sees for the Nab chunk shape, docs/Performance.md:16, and
+    larger): the filtered bytes must be the reference's -- odd waveform counts, a shorter last waveform, a general filter,
+    16 384-sample waveforms; damaged input is reported.  (Round 3 built a sliced form of this path -- upload, kernels and
+    download of waveform slices overlapped through a helper thread -- held it to these cases, and measured no gain: pageable
+    copies serialise inside the runtime, profiles/r03_notes.md.)"""
+    import deltarice_amd as dr
+    rng = np.random.default_rng(404)
+    for W, L, short, opts_tail in [(2000, 7000, 0, ()), (1237, 4099, 1234, ()), (700, 16384, 5000, ()), (1500, 3000, 0, (4, 1, 0xFFFFFFFF, 1, 0xFFFFFFFF))]:
+        n = W * L - short
+        x = rng.normal(0, 10, n).astype(np.int16)
+        opts = (8, L) + opts_tail
+        ref = O.encode_chunk(x, opts)
+        enc = ctx.filter_chunk(x, opts, reverse=False)
+        assert enc == ref.tobytes(), (W, L)
+        dec = ctx.filter_chunk(ref.tobytes(), opts, reverse=True)
+        assert dec == x.tobytes(), (W, L)
+        # a broken header chain 60 % into the chunk, a truncated chunk, damaged payload bits
+        bad = ref.copy()
+        pos, hops = 1, int(W * 0.6)
+        for _ in range(hops):
+            pos += int(bad[pos]) + 1
+        bad[pos] += 3
+        with pytest.raises(dr.DeltaRiceError) as ei:
+            ctx.filter_chunk(bad.tobytes(), opts, reverse=True)
+        assert ei.value.status == 4
+        with pytest.raises(dr.DeltaRiceError):
+            ctx.filter_chunk(ref[:-5].tobytes(), opts, reverse=True)
+        bad = ref.copy()
+        bad[pos + 40:pos + 43] ^= np.uint32(0x5A5A5A5A)
+        try:
+            assert len(ctx.filter_chunk(bad.tobytes(), opts, reverse=True)) == 2 * n
+        except dr.DeltaRiceError as e:
+            assert e.status == 4
+        assert ctx.filter_chunk(ref.tobytes(), opts, reverse=True) == x.tobytes()  # the context is still usable

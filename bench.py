@@ -179,10 +179,34 @@ def free_port():
     return p
 
 
+def visible_gpus():
+    """GPUs this process could use, counted WITHOUT touching HIP: KFD topology nodes that have SIMDs, cut down by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES.  (torch.cuda.device_count() falls through to hipGetDeviceCount on builds
+    without amdsmi, which starts the runtime in this process.)  None where the topology cannot be read."""
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def spawn_ranks(a):
-    """`--gpus N` without a launcher: start the N ranks here.  Nothing in this process has initialised the GPU
-    (torch.cuda.device_count() does not), so the children are ordinary fresh processes."""
-    have = torch.cuda.device_count()
+    """`--gpus N` without a launcher: start the N ranks here.  This process may initialise the HIP runtime (only as a last
+    resort, to count devices); it therefore only ever STARTS child processes and never execs -- the ranks are ordinary
+    fresh processes."""
+    have = visible_gpus()
+    if have is None:
+        have = torch.cuda.device_count()
     need = 1 if a.backend != "nccl" else a.gpus
     if have < need:
         raise SystemExit(f"bench.py: --gpus {a.gpus} needs {need} visible GPUs, this host shows {have}")
@@ -339,13 +363,13 @@ def main():
                               + ("; dropped: the kernel sources have changed since" if stale else "")
                               + (f"; in-run collection: {traffic_note}" if traffic_note else ""))
 
-    # every rank reports its device and encoded size: rank 0 prints what it SAW, not what it was told
-    rank_info = [[rank, local, total_words * 4]]
+    # every rank reports its device, encoded size and kernel times (microseconds): rank 0 prints what it SAW, not what it was told
+    rank_info = [[rank, local, total_words * 4, int(round(pack_ms * 1e3)), int(round(dec_kernel_ms * 1e3))]]
     if world > 1:
         t = torch.tensor(rank_info[0], dtype=torch.int64, device=dev if a.backend == "nccl" else "cpu")
-        allr = torch.empty(world * 3, dtype=torch.int64, device=t.device)
+        allr = torch.empty(world * 5, dtype=torch.int64, device=t.device)
         dist.all_gather_into_tensor(allr, t)
-        rank_info = allr.cpu().reshape(world, 3).tolist()
+        rank_info = allr.cpu().reshape(world, 5).tolist()
         if sorted(r[0] for r in rank_info) != list(range(world)):
             raise SystemExit(f"bench.py: ranks seen {rank_info}, expected 0..{world - 1}")
 
@@ -364,6 +388,8 @@ def main():
                        "decode_impl": a.decode_impl},
             "compression_ratio": ratio,
             "rank_devices": [r[1] for r in rank_info], "rank_encoded_bytes": [r[2] for r in rank_info],
+            # per-GPU kernel times next to the wall time: what every rank measured with HIP events on its own stream
+            "rank_kernel_ms": {"encode": [r[3] / 1e3 for r in rank_info], "decode": [r[4] / 1e3 for r in rank_info]},
             "backend": (a.backend if world > 1 else None),
             "encode_GBps": raw_bytes / (enc_ms[3] * 1e-3) / 1e9,
             "decode_GBps": raw_bytes / (dec_ms[3] * 1e-3) / 1e9,

@@ -232,7 +232,11 @@ int drx_ctx_device(const drx_ctx *c) { return c ? c->device : -1; }
 drx_status drx_ctx_set_option(drx_ctx *c, const char *key, int64_t value) {
     if (!c || !key) return DRX_ERR_ARG;
     if (!strcmp(key, "decode_impl")) {
+#ifdef DRX_LEGACY
         if (value != 0 && value != 1 && value != 5 && value != 7 && value != 8) return DRX_ERR_ARG;
+#else
+        if (value != 0 && value != 7 && value != 8) return DRX_ERR_ARG;  // (1 / 5: one sample per ring access, -DDRX_LEGACY builds)
+#endif
         c->decode_impl = (int)value;
         return DRX_OK;
     }

@@ -1,6 +1,6 @@
 // drx_blocks.hip -- block-parallel decoder: a WORKGROUP per block of a waveform's stream.
 //
-// The lane-per-waveform decoder (k_decode_lanes, drx_kernels.hip) needs ~10^5 waveforms to fill an MI355X.  The
+// The lane-per-waveform decoder (k_decode_lanes, drx_decode_kernels.hip) needs ~10^5 waveforms to fill an MI355X.  The
 // reference's own shapes often have far fewer: its default options make every chunk ONE waveform
 // (src/deltaRice.c:249-258), nEDM / NOPTREX chunks are 32 waveforms of 81 920 / 500 000 samples
 // (docs/Performance.md:27,38), and one H5Z call on the README's example chunk sees 20 waveforms
@@ -24,7 +24,7 @@
 //             chain); samples and the running sum in front of a block come from a decoupled look-back over the
 //             blocks of the waveform ({status | count | sum} entries, tickets as in the encoder).  A block that has to
 //             correct its start after it published its end flags the waveform; flagged waveforms are decoded again
-//             by the one-workgroup-per-waveform kernel (drx_kernels.hip), which is also the one that judges them.
+//             by the one-workgroup-per-waveform kernel (drx_decode_kernels.hip), which is also the one that judges them.
 //   phase 2   phase 1 has left every lane's running sums (relative to its first code) in LDS, lane-major; once the
 //             prefix sums over counts and sums are known each lane reads its own into registers, adds its base and
 //             writes them to the same buffer in OUTPUT order; the block then copies whole aligned 128-byte lines to

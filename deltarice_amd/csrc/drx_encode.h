@@ -1,5 +1,5 @@
 // Packed 16-bit Rice coding of a 512-sample tile (64 lanes x 8 samples) and its emission into an LDS bit buffer: shared by
-// the single-pass encoders (k_encode_fused in drx_kernels.hip, k_encode_pieces in drx_pieces.hip) and the segment
+// the single-pass encoders (k_encode_fused in drx_encode_kernels.hip, k_encode_pieces in drx_pieces.hip) and the segment
 // encoder.  Device code only; included by the .hip translation units.
 #ifndef DRX_ENCODE_H
 #define DRX_ENCODE_H

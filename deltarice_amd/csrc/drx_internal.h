@@ -71,7 +71,7 @@ struct Geom {
     // segment slot) of every chunk, n_chunks + 1 entries, and their total
     const uint64_t *seg_unit_base;
     uint64_t seg_units;
-    // ragged batches small enough for the parallel header walks (drx_kernels.hip): set when the plan is made;
+    // ragged batches small enough for the parallel header walks (drx_walk.h): set when the plan is made;
     // rag_bw_blocks_max = 4096-word blocks of the largest short-waveform chunk at 25 bits per sample
     uint32_t rag_par, rag_bw_blocks_max;
     uint32_t rag_bw_min_len;  // ... and the smallest WaveformLength among those chunks (bounds the headers of a block)
@@ -100,6 +100,18 @@ hipError_t launch_encode(const Geom &G, const int16_t *d_in, uint32_t *d_out, ui
                          uint64_t *d_chunk_word_off, uint32_t *d_wave_words, uint32_t *d_wave_rel,
                          uint64_t *d_chunk_words, DevStatus *d_status, hipEvent_t *ev, hipStream_t s);
 
+// launch_decode() takes the workgroup-per-waveform decoder for uniform batches whose lane-per-waveform decode would leave most of
+// the 98 304 lane slots empty and the block decoder does not take: at most 16 384 waveforms of at least 65 536 samples, or at most
+// 4 096 of at least 16 384 (measured crossover at 350 M samples: L = 32 768 lanes 2.2 ms / long 2.9 ms, L = 65 536 3.6 / 2.4 ms);
+// the same test sends such batches to the segment encoder where the pieces encoder does not apply
+__host__ __device__ inline bool long_waveform_batch(uint64_t total_waves, uint32_t wave_len) {
+    return (wave_len >= 65536u && total_waves <= 16384u) || (wave_len >= 16384u && total_waves <= 4096u);
+}
+static inline unsigned blocks_for(uint64_t items, unsigned per_block) { return (unsigned)((items + per_block - 1) / per_block); }
+static inline void mark(hipEvent_t *ev, int i, hipStream_t s) {  // (optional profiling events of a launch)
+    if (ev) (void)hipEventRecord(ev[i], s);
+}
+
 hipError_t launch_sideband_tables(const Geom &G, const uint32_t *d_in, uint64_t in_words, const uint64_t *d_chunk_word_off,
                                   const uint32_t *d_n, uint64_t *d_wave_off, uint32_t *d_wave_words, DevStatus *d_status, hipStream_t s);
 hipError_t launch_estimate_words(const Geom &G, const int16_t *d_in, unsigned long long *d_words16, hipStream_t s);
@@ -108,7 +120,7 @@ hipError_t launch_encode_fused(const Geom &G, const int16_t *d_in, uint32_t *d_o
                                uint64_t *d_chunk_word_off, uint32_t *d_wave_words, uint64_t *d_scan,
                                DevStatus *d_status, hipEvent_t *ev, hipStream_t s);
 
-// few long waveforms (WaveformLength = -1): a wavefront per 8192-sample segment, see drx_kernels.hip
+// few long waveforms (WaveformLength = -1): a wavefront per 8192-sample segment, see drx_encode_kernels.hip
 bool long_batch(const Geom &G);
 uint64_t long_batch_units(const Geom &G);
 hipError_t launch_encode_long(const Geom &G, const int16_t *d_in, uint32_t *d_out, uint64_t out_cap,
@@ -212,7 +224,7 @@ hipError_t launch_iir(const Geom &G, const uint64_t *d_chunk_tile_base, uint64_t
                       const uint32_t *d_skip, DevStatus *d_status, int16_t *d_out, hipStream_t s);
 uint64_t par_walk_scratch_bytes(const Geom &G);
 uint32_t bw_walk_blocks_max(const Geom &G);
-constexpr uint32_t kWalkShortLenHost = 2048;  // keep equal to kWalkShortLen in drx_kernels.hip
+constexpr uint32_t kWalkShortLenHost = 2048;  // keep equal to kWalkShortLen in drx_walk.h
 // WaveformLengths the segment encoder takes in any batch: up to kSegShortLenHost, and from kSegLongLenHost
 constexpr uint32_t kSegShortLenHost = 3072, kSegLongLenHost = 10240;
 // limits of the parallel header walks (see k_walk_parallel / k_bw_blocks)

@@ -1,5 +1,5 @@
 // drx_pieces.hip -- single-pass encoder for batches whose waveforms are much shorter or much longer than the
-// ~2000-8000 samples one wavefront of k_encode_fused (drx_kernels.hip) likes (gfx950).
+// ~2000-8000 samples one wavefront of k_encode_fused (drx_encode_kernels.hip) likes (gfx950).
 //
 // k_encode_fused gives a waveform to a wavefront: with WaveformLength 512 it pays a workgroup barrier, a share of a
 // look-back and an 8 KB LDS clear per 512 samples, and beyond ~10 000 samples the code outgrows the wavefront's LDS

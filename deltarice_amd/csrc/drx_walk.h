@@ -1,0 +1,821 @@
+// drx_walk.h -- the header-chain walk: device functions and kernels.  Included by drx_decode_kernels.hip alone (the decode
+// launch runs walkers inside k_decode_lanes and launches the walk kernels).
+//
+// The format's only way to waveform i + 1 is the length header of waveform i (src/deltaRice.c:320-325).  Four forms:
+//   scalar chains     one lane (eight scalar-load chains per wave) per chunk, hop by hop: inside the decode launch of large
+//                     batches, where the serial latency hides behind the decoding;
+//   LDS block walker  chunks of short waveforms streamed through LDS by a whole wave;
+//   chunk-wide walk   k_pw_scan + k_walk_parallel: candidate headers, binary lifting -- a handful of chunks of long waveforms;
+//   block-parallel    k_bw_blocks / k_bw_scan / k_bw_emit: every B-word block of a chunk of short waveforms holds a header.
+// Every walker validates while it walks (sample count, n_i bounds, the chain ends at the chunk's end).
+#ifndef DRX_WALK_H
+#define DRX_WALK_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "drx_internal.h"
+#include "drx_device.h"
+
+namespace drx {
+
+
+// Header chain walk (:320-325) with validation; one lane per chunk.
+// granules (optional): one 8-byte word per waveform, {valid:1 | n_i:31 | header position relative to
+// the chunk start:32}, stored with one agent-scope relaxed atomic each -- the word is its own flag
+// (it is zero until written), so a decoder wave in the SAME launch can consume waveform w of a
+// chunk while the walk of that chunk is still at waveform w+1.
+constexpr uint64_t kGranValid = 1ull << 63;
+
+__device__ __forceinline__ void walk_chunk(const Geom &G, uint64_t c, const uint32_t *__restrict__ in,
+                                           uint64_t in_words, const uint64_t *__restrict__ chunk_word_off,
+                                           uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
+                                           uint64_t *__restrict__ granules, DevStatus *st) {
+    uint64_t base;
+    uint32_t W, L, N;
+    if (G.uniform) { base = c * G.u_n_waves; W = G.u_n_waves; L = G.u_wave_len; N = G.u_n_samples; }
+    else { const ChunkDesc d = G.chunks[c]; base = d.wave_base; W = d.n_waves; L = d.wave_len; N = d.n_samples; }
+    const uint64_t begin = chunk_word_off[c];
+    uint64_t end = chunk_word_off[c + 1];
+    bool bad = false;
+    if (end > in_words || begin + 2 > end || end - begin > 0xffffffffull) { bad = true; end = begin; }
+    if (!bad && in[begin] != N) bad = true;  // :306 totalNumberPoints
+    uint64_t at = begin + 1;
+    for (uint32_t w = 0; w < W; ++w) {
+        uint32_t n = 0;
+        uint64_t here = at;
+        if (!bad && at < end) {
+            n = in[at];
+            const uint32_t len = (w + 1 == W) ? (N - w * L) : L;
+            if (n > max_payload_words(len) || n < min_payload_words(len, G.k) || at + 1u + n > end) { bad = true; n = 0; }
+            else at += (uint64_t)n + 1u;
+        } else {
+            bad = true;
+            here = begin;  // keeps later loads in bounds; decoded as zero words
+        }
+        wave_off[base + w] = here;
+        wave_words[base + w] = n;
+        if (granules)
+            __hip_atomic_store(granules + base + w, kGranValid | ((uint64_t)n << 32) | (uint64_t)(uint32_t)(here - begin),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!bad && at != end) bad = true;
+    if (bad) atomicOr(&st->err, kErrCorrupt);
+}
+
+// The same walk for kWalkChains chunks of a uniform batch per wavefront (lanes 0..kWalkChains-1), with the
+// header loads issued as SCALAR loads (s_load_dword through the scalar cache): under the decode's
+// ~3.6 TB/s of vector traffic a dependent vector load takes ~2.9 us per hop (it queues behind the other
+// waves' 64-line gathers in the CU's vector memory pipeline) and the chain becomes the critical path of
+// the fused launch; the scalar path does not share that queue.
+constexpr int kWalkChains = 8;
+
+__device__ __forceinline__ void walk_chunks_scalar(const Geom &G, uint64_t c0, const uint32_t *__restrict__ list,
+                                                   uint64_t n_list, const uint32_t *__restrict__ in,
+                                                   uint64_t in_words, const uint64_t *__restrict__ chunk_word_off,
+                                                   uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
+                                                   uint64_t *__restrict__ granules, DevStatus *st,
+                                                   const uint32_t *__restrict__ only = nullptr) {
+    // lanes 0..kWalkChains-1 take entries c0.. of the chunk list (list == nullptr: chunk index = entry);
+    // only != nullptr: just the chunks it flags (the ones k_walk_parallel gave up on)
+    const int lane = lane_id();
+    const uint64_t e = c0 + (uint64_t)lane;
+    bool mine = lane < kWalkChains && e < n_list;
+    const uint64_t c = mine ? (list ? (uint64_t)list[e] : e) : 0;
+    if (only && mine && !only[c]) mine = false;
+    if (only && !__any(mine)) return;
+    uint32_t W = 0, L = 1, N = 0;
+    uint64_t base = 0;
+    if (mine) {
+        if (G.uniform) { W = G.u_n_waves; L = G.u_wave_len; N = G.u_n_samples; base = c * W; }
+        else { const ChunkDesc d = G.chunks[c]; W = d.n_waves; L = d.wave_len; N = d.n_samples; base = d.wave_base; }
+    }
+    const uint32_t W_max = wave_max_u32(W);
+    uint64_t begin = 0, end = 0;
+    bool bad = false;
+    if (mine) {
+        begin = chunk_word_off[c];
+        end = chunk_word_off[c + 1];
+        if (end > in_words || begin + 2 > end || end - begin > 0xffffffffull) { bad = true; end = begin; }
+    }
+    if (in_words == 0) {  // nothing to load from (every chunk is bad)
+        if (mine) {
+            for (uint32_t w = 0; w < W; ++w) {
+                wave_off[base + w] = begin;
+                wave_words[base + w] = 0;
+                if (granules) __hip_atomic_store(granules + base + w, kGranValid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            atomicOr(&st->err, kErrCorrupt);
+        }
+        return;
+    }
+    // word `a` of the stream for lanes 0..kWalkChains-1 (a < in_words), one scalar load per chain
+    auto sload = [&](uint64_t a) __attribute__((always_inline)) -> uint32_t {
+        static_assert(kWalkChains == 8, "the asm block below issues eight loads");
+        uint64_t p[kWalkChains];
+#pragma unroll
+        for (int i = 0; i < kWalkChains; ++i) {
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)a, i);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(a >> 32), i);
+            p[i] = (uint64_t)(uintptr_t)(in + (((uint64_t)hi << 32) | lo));
+        }
+        uint32_t v0, v1, v2, v3, v4, v5, v6, v7;
+        // one block: all eight loads in flight before the wait (left to itself the compiler waits after seven)
+        asm volatile(
+            "s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %9, 0x0\n\ts_load_dword %2, %10, 0x0\n\t"
+            "s_load_dword %3, %11, 0x0\n\ts_load_dword %4, %12, 0x0\n\ts_load_dword %5, %13, 0x0\n\t"
+            "s_load_dword %6, %14, 0x0\n\ts_load_dword %7, %15, 0x0\n\ts_waitcnt lgkmcnt(0)"
+            : "=&s"(v0), "=&s"(v1), "=&s"(v2), "=&s"(v3), "=&s"(v4), "=&s"(v5), "=&s"(v6), "=&s"(v7)
+            : "s"(p[0]), "s"(p[1]), "s"(p[2]), "s"(p[3]), "s"(p[4]), "s"(p[5]), "s"(p[6]), "s"(p[7])
+            : "memory");
+        const uint32_t v[kWalkChains] = {v0, v1, v2, v3, v4, v5, v6, v7};
+        uint32_t r = 0;
+#pragma unroll
+        for (int i = 0; i < kWalkChains; ++i) r = (lane == i) ? v[i] : r;
+        return r;
+    };
+    const uint32_t head = sload((mine && !bad) ? begin : 0ull);
+    if (mine && !bad && head != N) bad = true;  // :306 totalNumberPoints
+    uint64_t at = begin + 1;
+    for (uint32_t w = 0; w < W_max; ++w) {
+        const bool live = mine && w < W;  // chunks of a ragged batch differ in their number of waveforms
+        const bool can = live && !bad && at < end;
+        const uint32_t nn = sload(can ? at : 0ull);
+        uint32_t n = 0;
+        uint64_t here = at;
+        if (can) {
+            n = nn;
+            const uint32_t len = (w + 1 == W) ? (N - w * L) : L;
+            if (n > max_payload_words(len) || n < min_payload_words(len, G.k) || at + 1u + n > end) { bad = true; n = 0; }
+            else at += (uint64_t)n + 1u;
+        } else if (live) {
+            bad = true;
+            here = begin;
+        }
+        if (live) {
+            wave_off[base + w] = here;
+            wave_words[base + w] = n;
+            if (granules)
+                __hip_atomic_store(granules + base + w, kGranValid | ((uint64_t)n << 32) | (uint64_t)(uint32_t)(here - begin),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (mine && !bad && at != end) bad = true;
+    if (mine && bad) atomicOr(&st->err, kErrCorrupt);
+}
+
+__global__ __launch_bounds__(64) void k_walk_scalar(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
+                                                    const uint64_t *__restrict__ chunk_word_off,
+                                                    uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
+                                                    DevStatus *st) {
+    walk_chunks_scalar(G, (uint64_t)blockIdx.x * kWalkChains, nullptr, G.n_chunks, in, in_words, chunk_word_off, wave_off,
+                       wave_words, nullptr, st);
+}
+
+__global__ __launch_bounds__(64) void k_walk_scalar_only(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
+                                                         const uint64_t *__restrict__ chunk_word_off,
+                                                         uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
+                                                         DevStatus *st, const uint32_t *__restrict__ only) {
+    walk_chunks_scalar(G, (uint64_t)blockIdx.x * kWalkChains, nullptr, G.n_chunks, in, in_words, chunk_word_off, wave_off,
+                       wave_words, nullptr, st, only);
+}
+
+// The header chain WITHOUT its 2000 dependent round trips, for batches of a handful of chunks (where nothing hides
+// them: 1.7 ms of a 2.2 ms decode).  A length header is a small number (n_i <= 25 bits per sample: 5469 for
+// L = 7000) and payload words are Rice-coded bits, which practically never start with 19 zero bits.  So:
+//   1. the whole chunk is read once (k_pw_scan, 16 workgroups per chunk) and every word <= that bound becomes a
+//      CANDIDATE header (the ~2000 real ones plus a few impostors); one workgroup per chunk sorts them by position;
+//   2. candidate i links to the candidate at position pos_i + n_i + 1 (binary search), to END if that is the chunk
+//      end, to INVALID if no candidate sits there;
+//   3. binary lifting over those links (up[k][i] = 2^k links ahead), then waveform w's header is w links from the
+//      candidate at word 1: eleven steps, every waveform in parallel.  Impostors are simply never reached.
+// Anything unexpected (too many candidates, a broken link, a chain that does not end at the chunk end) flags the
+// chunk, and the scalar-load walker walks -- and judges -- the flagged chunks afterwards.
+constexpr int kPwThreads = 1024;
+constexpr uint32_t kPwCap = 4096;      // candidates per chunk
+constexpr uint32_t kPwMaxParts = 128;  // slices of a chunk (pw_parts())
+constexpr uint32_t kPwStride = kPwCap + kPwMaxParts;  // a chunk's scratch: its candidates, then {first, count} of every slice
+constexpr int kPwLevels = 12;
+// (kPwMaxWaves, kPwMaxChunks: drx_internal.h)
+
+// workgroups that scan one chunk: enough of them to fill the chip when the chunks are few (one chunk of 2000 x 7000, what an
+// H5Z call brings: 128 instead of 16 took the walk from 0.113 to 0.070 ms, k_pw_scan itself 9 us)
+__host__ inline uint32_t pw_parts(uint32_t n_chunks) { return n_chunks <= 4u ? 128u : (n_chunks <= 32u ? 32u : 16u); }
+
+// 1. candidates of one slice of a chunk -> the chunk's list in global memory (cand: kPwCap x {pos, val} per chunk,
+//    cand_count: one counter per chunk, zeroed before the launch)
+__global__ __launch_bounds__(256) void k_pw_scan(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
+                                                 const uint64_t *__restrict__ chunk_word_off, const uint32_t *__restrict__ list,
+                                                 uint2 *__restrict__ cand, uint32_t *__restrict__ cand_count, uint32_t parts) {
+    const uint64_t c = list ? (uint64_t)list[blockIdx.x / parts] : blockIdx.x / parts;  // scratch is indexed by chunk
+    const uint32_t part = blockIdx.x % parts, tid = threadIdx.x;
+    const uint64_t begin = chunk_word_off[c], end = chunk_word_off[c + 1];
+    if (end > in_words || begin + 2 > end || end - begin > 0x7fffffffull) return;  // k_walk_parallel flags the chunk
+    const uint32_t len_w = (uint32_t)(end - begin);
+    const uint32_t wl = G.uniform ? G.u_wave_len : G.chunks[c].wave_len;
+    const uint32_t max_full = (uint32_t)(((uint64_t)wl * 25u + 31u) >> 5);
+    uint2 *clist = cand + c * kPwStride;
+    // the slice's candidates are collected in LDS and appended with ONE global atomic (2000 atomics on one counter
+    // cost 0.2 ms: same-address atomics serialise in the L2)
+    __shared__ uint2 s_list[kPwCap / 4];
+    __shared__ uint32_t s_n, s_base;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    auto consider = [&](uint32_t i, uint32_t v) __attribute__((always_inline)) {
+        if (i >= 1u && i < len_w && v <= max_full) {
+            const uint32_t k = atomicAdd(&s_n, 1u);
+            if (k < kPwCap / 4) s_list[k] = make_uint2(i, v);
+        }
+    };
+    // 16-byte loads, four in flight per thread (a dependent 4-byte load per word made this pass take as long as
+    // the serial walk it replaces); quads are aligned, the first one may start below the chunk
+    const uint32_t mis = (uint32_t)((((uintptr_t)in >> 2) + begin) & 3u);
+    const uint32_t *q0 = in + begin - mis;  // words before `begin` are ignored by consider()
+    const uint32_t n_quads = (len_w + mis + 3u) >> 2;
+    const bool vec_ok = begin >= mis;
+    const uint32_t per = (n_quads + parts - 1u) / parts;
+    const uint32_t q_lo = part * per, q_hi = (q_lo + per < n_quads) ? q_lo + per : n_quads;
+    constexpr uint32_t U = 4;
+    for (uint32_t qb = q_lo + tid; qb < q_hi; qb += 256u * U) {
+        uint4 v[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t qi = qb + u * 256u;
+            v[u] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+            if (qi < q_hi) {
+                const uint64_t w0 = begin - mis + 4ull * qi;  // absolute word index of the quad
+                if (vec_ok && w0 + 4u <= in_words) {
+                    v[u] = *reinterpret_cast<const uint4 *>(q0 + 4ull * qi);
+                } else {
+                    if (w0 + 0u < in_words && w0 + 0u >= begin) v[u].x = in[w0 + 0u];
+                    if (w0 + 1u < in_words && w0 + 1u >= begin) v[u].y = in[w0 + 1u];
+                    if (w0 + 2u < in_words && w0 + 2u >= begin) v[u].z = in[w0 + 2u];
+                    if (w0 + 3u < in_words && w0 + 3u >= begin) v[u].w = in[w0 + 3u];
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t i0 = 4u * (qb + u * 256u) - mis;  // may wrap below zero for the first quad: consider() rejects
+            consider(i0 + 0u, v[u].x);
+            consider(i0 + 1u, v[u].y);
+            consider(i0 + 2u, v[u].z);
+            consider(i0 + 3u, v[u].w);
+        }
+    }
+    __syncthreads();
+    const uint32_t n_loc = s_n;
+    if (n_loc > kPwCap / 4) {  // more candidates in one slice than a sane chunk has in four: let the serial walker judge
+        if (tid == 0) atomicAdd(cand_count + c, kPwCap);
+        return;
+    }
+    if (tid == 0) {
+        s_base = atomicAdd(cand_count + c, n_loc);
+        clist[kPwCap + part] = make_uint2(s_base, n_loc);  // k_walk_parallel puts the slices in order
+    }
+    __syncthreads();
+    // written in position order inside the slice (rank by counting: a slice holds tens of candidates), so that
+    // k_walk_parallel needs no sort
+    const uint32_t b0 = s_base;
+    for (uint32_t i = tid; i < n_loc; i += 256u) {
+        const uint2 e = s_list[i];
+        uint32_t r = 0;
+        for (uint32_t j = 0; j < n_loc; ++j) r += s_list[j].x < e.x ? 1u : 0u;
+        if (b0 + r < kPwCap) clist[b0 + r] = e;
+    }
+}
+
+__global__ __launch_bounds__(kPwThreads) void k_walk_parallel(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
+                                                              const uint64_t *__restrict__ chunk_word_off,
+                                                              uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
+                                                              uint32_t *__restrict__ fail, const uint32_t *__restrict__ list,
+                                                              const uint2 *__restrict__ cand, const uint32_t *__restrict__ cand_count,
+                                                              uint32_t parts) {
+    __shared__ uint32_t pos[kPwCap];   // candidate positions relative to the chunk start; padding entries sort last
+    __shared__ uint32_t val[kPwCap];
+    __shared__ uint16_t up[kPwLevels][kPwCap];
+    __shared__ uint32_t s_bad, s_start, s_first[kPwMaxParts], s_pre[kPwMaxParts + 1];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t c = list ? (uint64_t)list[blockIdx.x] : blockIdx.x;
+    uint32_t W, L, N;
+    uint64_t base;
+    if (G.uniform) { W = G.u_n_waves; L = G.u_wave_len; N = G.u_n_samples; base = c * W; }
+    else { const ChunkDesc d = G.chunks[c]; W = d.n_waves; L = d.wave_len; N = d.n_samples; base = d.wave_base; }
+    const uint64_t begin = chunk_word_off[c];
+    const uint64_t end = chunk_word_off[c + 1];
+    if (tid == 0) { s_bad = 0; s_start = 0xffffffffu; }
+    __syncthreads();
+    bool ok = !(end > in_words || begin + 2 > end || end - begin > 0x7fffffffull);
+    if (ok && in[begin] != N) ok = false;
+    if (!ok) { if (tid == 0) fail[c] = 1u; return; }  // (uniform across the workgroup)
+    const uint32_t len_w = (uint32_t)(end - begin);  // words in the chunk
+    const uint32_t max_full = (uint32_t)(((uint64_t)L * 25u + 31u) >> 5);
+    const uint32_t max_last = (uint32_t)(((uint64_t)(N - (W - 1) * L) * 25u + 31u) >> 5);
+    const uint32_t min_full = min_payload_words(L, G.k), min_last = min_payload_words(N - (W - 1) * L, G.k);
+    const uint32_t nc = cand_count[c];
+    if (nc > kPwCap - 2u || nc < W) { if (tid == 0) fail[c] = 1u; return; }
+    // the candidates in position order: k_pw_scan's slices cover the chunk in order and each wrote its own in order, so the
+    // slices only have to be put one behind the other (a bitonic sort of 4096 did this before: 78 barrier-separated stages)
+    if (tid < 64u) {
+        uint32_t run = 0;
+        for (uint32_t s0 = 0; s0 < parts; s0 += 64u) {
+            const uint32_t sl = s0 + tid;
+            uint2 e = make_uint2(0u, 0u);
+            if (sl < parts) e = cand[c * kPwStride + kPwCap + sl];
+            const uint32_t incl = wave_incl_scan_dpp(e.y);
+            if (sl < parts) { s_first[sl] = e.x; s_pre[sl + 1u] = run + incl; }
+            run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        if (tid == 0) s_pre[0] = 0;
+    }
+    __syncthreads();
+    if (s_pre[parts] != nc) { if (tid == 0) fail[c] = 1u; return; }  // (cannot happen: the slices' counts add up to it)
+    uint32_t n_pad = 64u;  // the candidates and the two sentinel nodes
+    while (n_pad < nc + 2u) n_pad <<= 1;
+    for (uint32_t i = tid; i < n_pad; i += kPwThreads) {
+        uint2 e = make_uint2(0xffffffffu, 0u);
+        if (i < nc) {
+            uint32_t lo = 0, hi = parts;  // invariant: s_pre[lo] <= i < s_pre[hi]
+            while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (s_pre[mid] <= i) lo = mid; else hi = mid; }
+            e = cand[c * kPwStride + s_first[lo] + (i - s_pre[lo])];
+        }
+        pos[i] = e.x;
+        val[i] = e.y;
+    }
+    __syncthreads();
+    // 2. links.  Nodes nc (END) and nc + 1 (INVALID) point to themselves.
+    const uint32_t END = nc, INV = nc + 1u;
+    for (uint32_t i = tid; i < n_pad; i += kPwThreads) {
+        uint32_t to = i;  // padding and the two sentinels: self loops
+        if (i < nc) {
+            const uint64_t target = (uint64_t)pos[i] + val[i] + 1u;
+            if (target == len_w) {
+                to = END;
+            } else if (target > len_w) {
+                to = INV;
+            } else {
+                uint32_t lo = 0, hi = nc;  // first candidate with pos >= target
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (pos[mid] < (uint32_t)target) lo = mid + 1u; else hi = mid; }
+                to = (lo < nc && pos[lo] == (uint32_t)target) ? lo : INV;
+            }
+            if (pos[i] == 1u) s_start = i;  // the first waveform's header follows the chunk header
+        }
+        up[0][i] = (uint16_t)to;
+    }
+    __syncthreads();
+    // 3. binary lifting
+    for (int k = 1; k < kPwLevels; ++k) {
+        for (uint32_t i = tid; i < n_pad; i += kPwThreads) up[k][i] = up[k - 1][up[k - 1][i]];
+        __syncthreads();
+    }
+    const uint32_t start = s_start;
+    if (start == 0xffffffffu) { if (tid == 0) fail[c] = 1u; return; }
+    bool bad = false;
+    for (uint32_t w = tid; w < W; w += kPwThreads) {
+        uint32_t node = start;
+#pragma unroll
+        for (int k = 0; k < kPwLevels; ++k)
+            if ((w >> k) & 1u) node = up[k][node];
+        if (node >= nc) { bad = true; continue; }
+        const uint32_t n = val[node];
+        if (n > ((w + 1u == W) ? max_last : max_full) || n < ((w + 1u == W) ? min_last : min_full)) { bad = true; continue; }
+        if (w + 1u == W && up[0][node] != END) { bad = true; continue; }
+        wave_off[base + w] = begin + pos[node];
+        wave_words[base + w] = n;
+    }
+    if (bad) atomicOr(&s_bad, 1u);
+    __syncthreads();
+    if (tid == 0 && s_bad) fail[c] = 1u;
+}
+
+__global__ __launch_bounds__(64) void k_walk_list(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
+                                                  const uint64_t *__restrict__ chunk_word_off,
+                                                  const uint32_t *__restrict__ chunk_list, uint32_t n_list,
+                                                  uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
+                                                  DevStatus *st) {
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    if (i >= n_list) return;
+    walk_chunk(G, chunk_list[i], in, in_words, chunk_word_off, wave_off, wave_words, nullptr, st);
+}
+
+// Header-chain walk for chunks of SHORT waveforms (one wavefront per chunk).  With n_i of a few
+// hundred words a chunk holds tens of thousands of waveforms and the per-hop HBM round trip of
+// walk_chunk() adds up to tens of milliseconds (27 343 hops for 14 M samples at L = 512).  Here the
+// wave streams the chunk through a 16 KB LDS block with coalesced 16-byte loads and lane 0 chases the
+// chain inside LDS (~0.07 us per hop); the price is one extra read of the chunk's stream.
+constexpr uint32_t kWalkBlockWords = 4096;
+constexpr uint32_t kWalkShortLen = 2048;  // WaveformLength up to which a chunk is walked through LDS
+
+constexpr uint32_t kWalkHopCap = 1024;   // hops buffered in LDS between coalesced flushes
+
+// blk: kWalkBlockWords words (16-byte aligned), hop: kWalkHopCap entries, both in LDS and private to the wave.
+__device__ __forceinline__ void walk_chunk_block(const Geom &G, uint64_t c, const uint32_t *__restrict__ in,
+                                                 uint64_t in_words, const uint64_t *__restrict__ chunk_word_off,
+                                                 uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
+                                                 uint64_t *__restrict__ granules, DevStatus *st, uint32_t *blk, uint2 *hop) {
+    constexpr uint32_t B = kWalkBlockWords;
+    constexpr int NV = B / 256;  // 16-byte loads per lane and block
+    const int lane = lane_id();
+    uint64_t base;
+    uint32_t W, L, N;
+    if (G.uniform) { base = c * G.u_n_waves; W = G.u_n_waves; L = G.u_wave_len; N = G.u_n_samples; }
+    else { const ChunkDesc d = G.chunks[c]; base = d.wave_base; W = d.n_waves; L = d.wave_len; N = d.n_samples; }
+    const uint64_t begin = chunk_word_off[c];
+    uint64_t end = chunk_word_off[c + 1];
+    bool bad = false;
+    if (end > in_words || begin + 2 > end || end - begin > 0xffffffffull) { bad = true; end = begin; }
+    if (!bad && in[begin] != N) bad = true;
+    const uint32_t max_full = (uint32_t)(((uint64_t)L * 25u + 31u) >> 5);
+    const uint32_t max_last = W ? (uint32_t)(((uint64_t)(N - (W - 1) * L) * 25u + 31u) >> 5) : 0u;
+    const uint32_t min_full = min_payload_words(L, G.k), min_last = W ? min_payload_words(N - (W - 1) * L, G.k) : 0u;
+    // blocks on a fixed grid from g0 (16-byte aligned when the stream is), so that block k + 1 can be
+    // requested before the chase through block k starts
+    const bool vec_ok = ((uintptr_t)in & 15u) == 0;
+    const uint64_t g0 = begin & ~3ull;
+    uint64_t at = begin + 1;  // header of waveform w (wave uniform)
+    uint32_t w = 0;
+    uint4 pre[NV];
+    uint64_t pre_b0 = ~0ull;  // block the registers hold
+    auto request = [&](uint64_t b0) __attribute__((always_inline)) {
+        pre_b0 = b0;
+        if (vec_ok && b0 + B <= end) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) pre[j] = *reinterpret_cast<const uint4 *>(in + b0 + (uint32_t)(j * 64 + lane) * 4u);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const uint64_t i = b0 + (uint32_t)(j * 64 + lane) * 4u;
+                uint4 v;
+                v.x = (i + 0u < end) ? in[i + 0u] : 0u;
+                v.y = (i + 1u < end) ? in[i + 1u] : 0u;
+                v.z = (i + 2u < end) ? in[i + 2u] : 0u;
+                v.w = (i + 3u < end) ? in[i + 3u] : 0u;
+                pre[j] = v;
+            }
+        }
+    };
+    if (!bad) request(g0);
+    while (w < W && !bad && at < end) {
+        const uint64_t b0 = g0 + (at - g0) / B * B;
+        if (pre_b0 != b0) request(b0);  // a hop longer than a block skipped the requested one
+#pragma unroll
+        for (int j = 0; j < NV; ++j) *reinterpret_cast<uint4 *>(blk + (uint32_t)(j * 64 + lane) * 4u) = pre[j];
+        wave_sync();
+        if (b0 + B < end) request(b0 + B);
+        const uint32_t blk_len = (end - b0 < B) ? (uint32_t)(end - b0) : B;
+        const uint32_t end_rel = (end - b0 < 0xffffffffull) ? (uint32_t)(end - b0) : 0xffffffffu;
+        uint32_t rel = (uint32_t)(at - b0);
+        while (w < W && rel < blk_len && !bad) {
+            // chase up to kWalkHopCap hops inside the block; every value here is wave uniform (SGPRs)
+            const uint32_t w0 = w;
+            uint32_t hops = 0;
+            while (w < W && rel < blk_len && hops < kWalkHopCap) {
+                const uint32_t n = __builtin_amdgcn_readfirstlane(blk[rel]);
+                const uint32_t lim = (w + 1 == W) ? max_last : max_full, lim_lo = (w + 1 == W) ? min_last : min_full;
+                if (n > lim || n < lim_lo || rel + 1u + n > end_rel) { bad = true; break; }
+                hop[hops] = make_uint2(rel, n);
+                rel += n + 1u;
+                ++w;
+                ++hops;
+            }
+            wave_sync();
+            for (uint32_t i = lane; i < hops; i += 64) {
+                const uint2 h = hop[i];
+                wave_off[base + w0 + i] = b0 + h.x;
+                wave_words[base + w0 + i] = h.y;
+                if (granules)
+                    __hip_atomic_store(granules + base + w0 + i,
+                                       kGranValid | ((uint64_t)h.y << 32) | (uint64_t)(uint32_t)(b0 + h.x - begin),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            wave_sync();
+        }
+        at = b0 + rel;
+    }
+    if (w < W) bad = true;
+    if (!bad && at != end) bad = true;
+    if (bad) {
+        for (uint32_t i = w + lane; i < W; i += 64) {
+            wave_off[base + i] = begin;
+            wave_words[base + i] = 0;
+            if (granules) __hip_atomic_store(granules + base + i, kGranValid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) atomicOr(&st->err, kErrCorrupt);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_walk_block(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
+                                                   const uint64_t *__restrict__ chunk_word_off,
+                                                   const uint32_t *__restrict__ chunk_list, uint32_t n_list,
+                                                   uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
+                                                   DevStatus *st) {
+    __shared__ __attribute__((aligned(16))) uint32_t blk[kWalkBlockWords];
+    __shared__ __attribute__((aligned(8))) uint2 hop[kWalkHopCap];  // {position in the block, n}
+    if (blockIdx.x >= n_list) return;
+    const uint64_t c = chunk_list ? chunk_list[blockIdx.x] : blockIdx.x;
+    walk_chunk_block(G, c, in, in_words, chunk_word_off, wave_off, wave_words, nullptr, st, blk, hop);
+}
+
+// The same idea for chunks of SHORT waveforms (tens of thousands of headers per chunk: too many for one
+// workgroup's LDS, and the chain chase through LDS still costs 0.13 us per hop, 3.6 ms for 14 M samples at
+// L = 512).  A header is at most max_words = 25 L / 32 (400 for L = 512) and every B-word block of the stream with
+// B > max_words holds at least one, so the BLOCKS become independent: a wavefront loads its block, takes the first word in
+// [1, max_words] as the block's entry header, chases the chain through LDS to the block's end (if the chain breaks,
+// the entry was an impostor: try the next small word), and reports {entry, headers, exit}.  k_bw_scan checks per
+// chunk that every block's exit is the next block's entry (and word 1 / the chunk end at the two ends) and
+// turns the counts into first-waveform indices; k_bw_blocks then runs again and writes the table.  A chunk
+// that does not stitch is flagged and walked by k_walk_block.
+// Launch shape.  How many blocks a chunk really has is only known on the device (chunk_word_off), while the host can only
+// bound it by 25 bits per sample, four times the usual: a grid with a workgroup per POSSIBLE block spent most of its time
+// on empty workgroups, each holding its LDS for a few microseconds.  So the grid is a fixed number of wavefronts (as many as
+// the LDS lets the chip hold) that stride over the REAL blocks, numbered through a prefix sum over the chunks' block
+// counts that every wavefront computes for itself (at most kBwMaxList chunks).  B is the smallest of 1024 / 2048 / 4096
+// that exceeds max_words: the chase is a chain of dependent LDS reads, so what hides it is wavefronts per CU, i.e.
+// little LDS per block.  (A one-pass version -- blocks in ticket order, {headers, exit} through a decoupled look-back,
+// table written straight from LDS -- was built and measured SLOWER than the two passes, 0.97 against 0.88 ms on config 5:
+// the frontier of known prefixes advances one window of entries per memory round trip; profiles/r02_notes.md.)
+constexpr uint32_t kBwTries = 6;  // impostors tolerated in front of a block's first real header
+constexpr uint32_t kBwMaxList = 256;  // chunks per launch (bw_walk_blocks_max() / the plan admit at most 224)
+
+struct BwBlock { uint32_t entry, count, exit, base; };
+
+// pre[s] = real blocks of the listed chunks in front of chunk s (pre[n_list] = all); a chunk whose extent is unusable has
+// none (k_bw_scan flags it), one longer than the host's bound is cut there (ditto)
+template <uint32_t B>
+__device__ __forceinline__ void bw_block_prefix(const uint64_t *__restrict__ chunk_word_off, uint64_t in_words,
+                                                const uint32_t *__restrict__ list, uint32_t n_list, uint32_t blocks_max,
+                                                uint32_t *pre, int lane) {
+    uint32_t run = 0;
+    for (uint32_t s0 = 0; s0 < n_list; s0 += 64u) {
+        const uint32_t sl = s0 + (uint32_t)lane;
+        uint32_t nb = 0;
+        if (sl < n_list) {
+            const uint64_t c = list ? (uint64_t)list[sl] : sl;
+            const uint64_t begin = chunk_word_off[c], end = chunk_word_off[c + 1];
+            const bool bad = end > in_words || begin + 2 > end || end - begin > 0x7fffffffull;
+            if (!bad) nb = (uint32_t)((end - begin + B - 1u) / B);
+            if (nb > blocks_max) nb = blocks_max;
+        }
+        const uint32_t incl = wave_incl_scan_dpp(nb);
+        if (sl < n_list) pre[sl + 1u] = run + incl;
+        run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    if (lane == 0) pre[0] = 0;
+    wave_sync();
+}
+
+template <uint32_t B, bool EMIT, bool LIST = false>
+__global__ __launch_bounds__(64) void k_bw_blocks(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
+                                                  const uint64_t *__restrict__ chunk_word_off, const uint32_t *__restrict__ list,
+                                                  uint32_t n_list, uint32_t blocks_max,
+                                                  BwBlock *__restrict__ info, const uint32_t *__restrict__ fail,
+                                                  uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
+                                                  DevStatus *st, uint32_t *__restrict__ hops, uint32_t hop_cap) {
+    constexpr int NV = B / 256;
+    __shared__ __attribute__((aligned(16))) uint32_t blk[B];
+    __shared__ uint16_t hop[EMIT ? B / 2 : 2];  // header positions inside the block (a waveform has at least one payload word)
+    __shared__ uint32_t pre[kBwMaxList + 1];
+    const int lane = lane_id();
+    bw_block_prefix<B>(chunk_word_off, in_words, list, n_list, blocks_max, pre, lane);
+    const uint32_t total = pre[n_list];
+    for (uint32_t unit = blockIdx.x; unit < total; unit += gridDim.x) {
+        wave_sync();  // (the previous block's LDS reads are done)
+        uint32_t lo = 0, hi = n_list;  // invariant: pre[lo] <= unit < pre[hi]
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (pre[mid] <= unit) lo = mid; else hi = mid;
+        }
+        const uint32_t slot = lo, b = unit - pre[lo];
+        const uint64_t c = list ? (uint64_t)list[slot] : slot;
+        if (EMIT && fail[c]) continue;
+        uint32_t W, L, n_samples;
+        uint64_t wbase;
+        if (G.uniform) { W = G.u_n_waves; L = G.u_wave_len; n_samples = G.u_n_samples; wbase = c * W; }
+        else { const ChunkDesc d = G.chunks[c]; W = d.n_waves; L = d.wave_len; n_samples = d.n_samples; wbase = d.wave_base; }
+        const uint64_t begin = chunk_word_off[c], end = chunk_word_off[c + 1];
+        const uint32_t len_w = (uint32_t)(end - begin);  // (a chunk with an unusable extent has no blocks)
+        const uint32_t b0 = b * B;  // block = words [b0, b0 + B) of the chunk
+        if (b0 >= len_w) continue;   // (only a chunk cut at the host's bound; flagged by k_bw_scan)
+        const uint32_t blk_len = len_w - b0 < B ? len_w - b0 : B;
+        const uint32_t max_full = (uint32_t)(((uint64_t)L * 25u + 31u) >> 5);
+        const uint32_t min_words = min_payload_words(L, G.k);
+        // the block's words into LDS (a fixed grid of 16-byte quads relative to the block)
+        {
+            const uint64_t a0 = begin + b0;
+            const bool vec_ok = (((uintptr_t)(in + a0)) & 15u) == 0;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const uint32_t i = (uint32_t)(j * 64 + lane) * 4u;
+                uint4 v;
+                if (vec_ok && i + 4u <= blk_len) {
+                    v = *reinterpret_cast<const uint4 *>(in + a0 + i);
+                } else {
+                    v.x = (i + 0u < blk_len) ? in[a0 + i + 0u] : 0xffffffffu;
+                    v.y = (i + 1u < blk_len) ? in[a0 + i + 1u] : 0xffffffffu;
+                    v.z = (i + 2u < blk_len) ? in[a0 + i + 2u] : 0xffffffffu;
+                    v.w = (i + 3u < blk_len) ? in[a0 + i + 3u] : 0xffffffffu;
+                }
+                *reinterpret_cast<uint4 *>(blk + i) = v;
+            }
+        }
+        wave_sync();
+        if (!EMIT) {
+            // candidates in position order: the first word in [1, max_words] at or after `from` (word 0 of the chunk is its
+            // sample count: block 0 starts at word 1), 256 words per step.  Never 0: a waveform has at least one payload
+            // word, while the zero-padded LAST word of a waveform is all zeros whenever its final code ends in zero bits --
+            // an impostor that would chain straight into the real header behind it
+            uint32_t from = b == 0 ? 1u : 0u;
+            uint32_t entry = 0xffffffffu, count = 0, exit_pos = 0;
+            bool found = false;
+            for (uint32_t t = 0; t < kBwTries && !found; ++t) {
+                uint32_t first = 0xffffffffu;
+                for (uint32_t base = from & ~255u; base < blk_len; base += 256u) {
+                    const uint32_t i = base + 4u * (uint32_t)lane;
+                    const uint4 v = *reinterpret_cast<const uint4 *>(blk + i);  // (all B words were written above)
+                    uint32_t f = 0xffffffffu;
+                    if (i + 3u >= from && i + 3u < blk_len && v.w - 1u < max_full) f = i + 3u;
+                    if (i + 2u >= from && i + 2u < blk_len && v.z - 1u < max_full) f = i + 2u;
+                    if (i + 1u >= from && i + 1u < blk_len && v.y - 1u < max_full) f = i + 1u;
+                    if (i + 0u >= from && i + 0u < blk_len && v.x - 1u < max_full) f = i + 0u;
+                    first = ~wave_max_u32(~f);  // minimum over the wave
+                    if (first != 0xffffffffu) break;
+                }
+                if (first == 0xffffffffu) break;
+                // chase from `first` to the block's end
+                uint32_t rel = first, cnt = 0;
+                bool ok = true;
+                while (rel < blk_len) {
+                    const uint32_t n = __builtin_amdgcn_readfirstlane(blk[rel]);
+                    // (n == 0 is no waveform: at least one bit per sample; it also bounds the headers of a block by B / 2)
+                    if (n - 1u >= max_full || (uint64_t)b0 + rel + 1u + n > len_w) { ok = false; break; }
+                    if (LIST) {
+                        // the header list for k_bw_emit: {position in the block, n}.  Its capacity counts on at least 1 + k
+                        // bits per sample (min_words) for every waveform but the chunk's last, shorter one
+                        if ((n < min_words && b0 + rel + 1u + n != len_w) || cnt >= hop_cap) { ok = false; break; }
+                        if (lane == 0) hops[(uint64_t)unit * hop_cap + cnt] = rel | (n << 12);
+                    }
+                    rel += n + 1u;
+                    ++cnt;
+                }
+                if (ok) { found = true; entry = first; count = cnt; exit_pos = b0 + rel; }
+                else from = first + 1u;
+            }
+            if (lane == 0) {
+                BwBlock o;
+                o.entry = found ? b0 + entry : 0xffffffffu;
+                o.count = count;
+                o.exit = exit_pos;
+                o.base = 0;
+                info[unit] = o;
+            }
+            continue;
+        }
+        // EMIT: chase again from the accepted entry, then write the block's part of the table
+        const BwBlock me = info[unit];
+        if (me.entry == 0xffffffffu) continue;  // a last block without a header (k_bw_scan)
+        uint32_t rel = me.entry - b0, hops = 0;
+        while (rel < blk_len) {
+            const uint32_t n = __builtin_amdgcn_readfirstlane(blk[rel]);
+            if (lane == 0) hop[hops] = (uint16_t)rel;
+            rel += n + 1u;
+            ++hops;
+        }
+        wave_sync();
+        for (uint32_t i = (uint32_t)lane; i < hops; i += 64u) {
+            const uint32_t pos = hop[i], n = blk[pos], wi = me.base + i;  // (k_bw_scan accepted the chunk: wi < W)
+            wave_off[wbase + wi] = begin + b0 + pos;
+            wave_words[wbase + wi] = n;
+            // the chunk's last waveform may be shorter than the rest: its header has tighter bounds; and no
+            // header may be below the minimum of 1 + k bits per sample (the chase only checked the upper bound)
+            if (wi + 1u == W) {
+                const uint32_t last_len = n_samples - (W - 1u) * L;
+                if (n > max_payload_words(last_len) || n < min_payload_words(last_len, G.k)) atomicOr(&st->err, kErrCorrupt);
+            } else if (n < min_payload_words(L, G.k)) {
+                atomicOr(&st->err, kErrCorrupt);
+            }
+        }
+    }
+}
+
+// one wavefront per chunk: stitch the blocks, first-waveform index of every block, verdict
+template <uint32_t B>
+__global__ __launch_bounds__(64) void k_bw_scan(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
+                                                const uint64_t *__restrict__ chunk_word_off, const uint32_t *__restrict__ list,
+                                                uint32_t n_list, uint32_t blocks_max, BwBlock *__restrict__ info,
+                                                uint32_t *__restrict__ fail) {
+    __shared__ uint32_t pre[kBwMaxList + 1];
+    const int lane = lane_id();
+    bw_block_prefix<B>(chunk_word_off, in_words, list, n_list, blocks_max, pre, lane);
+    const uint64_t slot = blockIdx.x;
+    const uint64_t c = list ? (uint64_t)list[slot] : slot;
+    uint32_t W, L, N;
+    if (G.uniform) { W = G.u_n_waves; L = G.u_wave_len; N = G.u_n_samples; }
+    else { const ChunkDesc d = G.chunks[c]; W = d.n_waves; L = d.wave_len; N = d.n_samples; }
+    const uint64_t begin = chunk_word_off[c], end = chunk_word_off[c + 1];
+    bool bad = end > in_words || begin + 2 > end || end - begin > 0x7fffffffull;
+    if (!bad && in[begin] != N) bad = true;
+    const uint32_t len_w = bad ? 0u : (uint32_t)(end - begin);
+    const uint32_t n_blocks = (len_w + B - 1u) / B;
+    if (n_blocks > blocks_max) bad = true;
+    BwBlock *my = info + pre[slot];
+    uint32_t run = 0;
+    for (uint32_t b0 = 0; b0 < n_blocks && !bad; b0 += 64) {
+        const uint32_t b = b0 + (uint32_t)lane;
+        BwBlock o{0xffffffffu, 0, 0, 0};
+        if (b < n_blocks) o = my[b];
+        // every block must have been entered, start where its predecessor left, and the ends must be the chunk's
+        uint32_t prev_exit = (uint32_t)__shfl_up((int)o.exit, 1);
+        if (lane == 0) prev_exit = b0 ? my[b0 - 1u].exit : 1u;
+        bool lane_bad = false;
+        if (b < n_blocks) {
+            if (b + 1u == n_blocks && b > 0u && prev_exit == len_w) {
+                // the chain already ended inside the previous block: the last block is the tail of the last payload and
+                // has no header of its own (whatever small word it may hold is not one)
+                o.count = 0;
+                my[b].entry = 0xffffffffu;
+                my[b].count = 0;
+            } else {
+                lane_bad = o.entry == 0xffffffffu || o.entry != prev_exit;
+                if (b + 1u == n_blocks && o.exit != len_w) lane_bad = true;
+            }
+        }
+        if (__any(lane_bad)) { bad = true; break; }
+        const uint32_t inc = wave_incl_scan_dpp(b < n_blocks ? o.count : 0u);
+        if (b < n_blocks) my[b].base = run + inc - o.count;
+        run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    }
+    if (!bad && run != W) bad = true;
+    // the last waveform may be shorter: its header has a tighter bound than the blocks checked
+    if (lane == 0) fail[c] = bad ? 1u : 0u;
+    (void)L;
+}
+
+// Second pass where the first one left the header list (bw_hop_cap() != 0): a wavefront per block, striding over the real
+// blocks as above, copies {position, n} into the table at the index k_bw_scan gave the block.  No LDS, no second read of
+// the stream, no second chase (config 5: 0.185 -> 0.03 ms).
+template <uint32_t B>
+__global__ __launch_bounds__(256) void k_bw_emit(Geom G, uint64_t in_words, const uint64_t *__restrict__ chunk_word_off,
+                                                 const uint32_t *__restrict__ list, uint32_t n_list, uint32_t blocks_max,
+                                                 const BwBlock *__restrict__ info, const uint32_t *__restrict__ fail,
+                                                 const uint32_t *__restrict__ hops, uint32_t hop_cap,
+                                                 uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words, DevStatus *st) {
+    __shared__ uint32_t pre[kBwMaxList + 1];
+    const int lane = lane_id();
+    const uint32_t wv = threadIdx.x >> 6;
+    if (wv == 0) bw_block_prefix<B>(chunk_word_off, in_words, list, n_list, blocks_max, pre, lane);
+    __syncthreads();
+    const uint32_t total = pre[n_list];
+    for (uint32_t unit = blockIdx.x * 4u + wv; unit < total; unit += gridDim.x * 4u) {
+        uint32_t lo = 0, hi = n_list;  // invariant: pre[lo] <= unit < pre[hi]
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (pre[mid] <= unit) lo = mid; else hi = mid;
+        }
+        const uint32_t slot = lo, b = unit - pre[lo];
+        const uint64_t c = list ? (uint64_t)list[slot] : slot;
+        if (fail[c]) continue;
+        const BwBlock me = info[unit];
+        if (me.entry == 0xffffffffu) continue;  // a last block without a header (k_bw_scan)
+        uint32_t W, L, n_samples;
+        uint64_t wbase;
+        if (G.uniform) { W = G.u_n_waves; L = G.u_wave_len; n_samples = G.u_n_samples; wbase = c * W; }
+        else { const ChunkDesc d = G.chunks[c]; W = d.n_waves; L = d.wave_len; n_samples = d.n_samples; wbase = d.wave_base; }
+        const uint64_t at = chunk_word_off[c] + (uint64_t)b * B;
+        for (uint32_t i = (uint32_t)lane; i < me.count; i += 64u) {
+            const uint32_t h = hops[(uint64_t)unit * hop_cap + i], pos = h & 0xfffu, n = h >> 12, wi = me.base + i;
+            wave_off[wbase + wi] = at + pos;
+            wave_words[wbase + wi] = n;
+            // the chunk's last waveform may be shorter than the rest: its header has tighter bounds (the others were held
+            // to [min, max] by the chase)
+            if (wi + 1u == W) {
+                const uint32_t last_len = n_samples - (W - 1u) * L;
+                if (n > max_payload_words(last_len) || n < min_payload_words(last_len, G.k)) atomicOr(&st->err, kErrCorrupt);
+            }
+        }
+    }
+}
+
+// capacity of a block's header list (0: the batch keeps the second chase): B-word blocks hold at most B / (min_words + 1)
+// headers + the chunk's last.  Waveforms of fewer than 32 words keep the second chase: one lane's store per header costs
+// more than it saves there (100 chunks of 14 M samples, walk with lists / with the second chase: L = 64 2.85 / 2.44 ms,
+// 128 1.59 / 1.44, 512 0.64 / 0.73, 1024 0.48 / 0.64, 2048 0.45 / 0.68, 3072 0.55 / 0.97)
+__host__ inline uint32_t bw_hop_cap(uint32_t B, uint32_t min_len, uint32_t k) {
+    const uint32_t mw = min_payload_words(min_len, k);
+    if (mw < 32u || B > 4096u) return 0u;
+    return B / (mw + 1u) + 2u;
+}
+
+__global__ __launch_bounds__(64) void k_walk_block_only(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
+                                                        const uint64_t *__restrict__ chunk_word_off,
+                                                        uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
+                                                        DevStatus *st, const uint32_t *__restrict__ only) {
+    __shared__ __attribute__((aligned(16))) uint32_t blk[kWalkBlockWords];
+    __shared__ __attribute__((aligned(8))) uint2 hop[kWalkHopCap];
+    const uint64_t c = blockIdx.x;
+    if (c >= G.n_chunks || !only[c]) return;
+    walk_chunk_block(G, c, in, in_words, chunk_word_off, wave_off, wave_words, nullptr, st, blk, hop);
+}
+
+}  // namespace drx
+#endif

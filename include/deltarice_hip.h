@@ -165,11 +165,11 @@ drx_status drx_plan_last_timings(drx_plan *plan, float ms[4]);
 /* Tuning / diagnostics.  Returns DRX_ERR_ARG for unknown keys or values.
  *   "profile"      1: bracket the kernels with HIP events (drx_plan_last_timings)
  *   "encode_impl"  1 (default): single pass with look-back;  0: size pass + scan + pack pass
- *   "decode_impl"  variant of the lane-per-waveform decode kernel; each is bit-exact and covered by the parity tests
- *        (they exist as cross-checks of one another; measured losers of earlier rounds are in the git history):
- *        8 (default)  header walk inside the launch, two samples per ring access     7  the same, separate walk kernel
- *        5 / 1        one sample per ring access (fused / separate walk)             0  simple kernel (also: general filters
- *                                                                                       the staged kernel does not take)
+ *   "decode_impl"  variant of the lane-per-waveform decode; each is bit-exact and covered by the parity tests:
+ *        8 (default)  header walk inside the launch where the batch is large enough to hide it
+ *        7            the same kernel behind a separate walk kernel
+ *        0            simple kernel (also: general filters the staged kernel does not take)
+ *        (5 / 1: one sample per ring access, the form 8 / 7 superseded in round 1 -- only in builds made with -DDRX_LEGACY)
  *   "debug_flags"  dispatch overrides that force an alternative (still bit-exact) path, for tests and A/B timing:
  *        256 never the long-waveform paths, 512 long waveforms one workgroup each, 2048 never the parallel header walks,
  *        4096 never the pieces encoder, 8192 always the segment encoder, 32768 the pieces encoder also where one wavefront per

@@ -115,7 +115,7 @@ def main():
             expect = x
             if not lossless:
                 expect = np.concatenate([O.decode_chunk(ww, opts) for ww in words])
-            for flags, impl in ((0, 8), (256, 8), (512, 8), (0, 7), (0, 1), (0, 0), (0, 5)):
+            for flags, impl in ((0, 8), (256, 8), (512, 8), (0, 7), (256, 7), (0, 0), (131072, 8)):
                 ctx.set_option("debug_flags", flags)
                 ctx.set_option("decode_impl", impl)
                 log(f"  decode flags {flags} impl {impl}")
@@ -139,7 +139,7 @@ def main():
                     if j not in hdr:
                         bad[j] ^= np.uint32(1 << int(rng.integers(0, 32)))
                 encb = dr.EncodedBatch(dev(ctx, bad.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), bad.size)
-                for flags, impl in ((0, 8), (256, 8), (512, 8), (0, 1), (0, 0)):
+                for flags, impl in ((0, 8), (256, 8), (512, 8), (0, 7), (0, 0)):
                     ctx.set_option("debug_flags", flags)
                     ctx.set_option("decode_impl", impl)
                     log(f"  corrupt decode flags {flags} impl {impl}")

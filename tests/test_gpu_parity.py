@@ -56,7 +56,7 @@ def gpu_encode(ctx, plan, x):
     return enc, w, off
 
 
-IMPLS = [0, 1, 5, 7, 8]  # every decode_impl the ABI offers (include/deltarice_hip.h)
+IMPLS = [0, 7, 8]  # every decode_impl the default build offers (include/deltarice_hip.h; 1 / 5 are -DDRX_LEGACY builds')
 
 
 # --------------------------------------------------------------------------- golden
@@ -554,7 +554,7 @@ def test_short_waveform_chunks_walk_through_lds(ctx, O):
         ref_w, ref_off = O.encode_batch(x, W * L, opts)
         plan = ctx.plan_uniform(n_chunks, W * L, opts)
         enc = type(plan.encode(dev(ctx, x)))(dev(ctx, ref_w.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), ref_w.size)
-        for impl in (0, 1, 5, 7, 8):
+        for impl in IMPLS:
             ctx.set_option("decode_impl", impl)
             assert np.array_equal(plan.decode(enc).cpu().numpy(), x), (L, impl)
         ctx.set_option("decode_impl", 8)
@@ -839,3 +839,11 @@ def test_large_chunks_through_the_host_path(ctx, O):
         except dr.DeltaRiceError as e:
             assert e.status == 4
         assert ctx.filter_chunk(ref.tobytes(), opts, reverse=True) == x.tobytes()  # the context is still usable
+
+
+def test_legacy_decode_variants_are_not_in_the_default_build(ctx):
+    import deltarice_amd as dr
+    for impl in (1, 5, 2, 9):
+        with pytest.raises(dr.DeltaRiceError):
+            ctx.set_option("decode_impl", impl)
+    ctx.set_option("decode_impl", 8)

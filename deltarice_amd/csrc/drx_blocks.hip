@@ -48,7 +48,10 @@ constexpr int kBlkSegW = 11;             // words per lane (odd): 54 samples at 
 constexpr uint32_t kBlkLaneCap = 76;     // samples a lane can leave in its share of the staging buffer (+ 4.8 sigma)
 constexpr uint32_t kBlkLaneStride = kBlkLaneCap / 2u + 1u;  // dwords per lane: 38 of samples + a dump slot (odd: no bank conflicts)
 constexpr uint32_t kBlkPre = 8;          // words kept in front of a block: lane 0's run-up
-constexpr uint32_t kBlkGuessBits = 128;  // run-up in front of a segment (a parse is in step after a few codes; 96, 128,
+#ifndef DRX_BLK_GUESS_BITS
+#define DRX_BLK_GUESS_BITS 128
+#endif
+constexpr uint32_t kBlkGuessBits = DRX_BLK_GUESS_BITS;  // run-up in front of a segment (a parse is in step after a few codes; 96, 128,
                                          // 160 and 224 bits measured: within 4 % of one another, profiles/r02_notes.md)
 constexpr uint32_t kBlkRun = 4;          // consecutive blocks of a waveform per ticket, when waveforms outnumber workgroups
 constexpr uint32_t kBlkTail = 4;         // words behind a block: a code that starts inside may end 24 bits behind it,
@@ -160,9 +163,15 @@ __device__ __forceinline__ uint32_t unzigzag(uint32_t z) { return (z >> 1) ^ (0u
 // second loop cost what the masks had: profiles/r02_notes.md.)
 // RESID: the RESIDUALS themselves are staged / stored instead of their running sums (general prediction filters: the inverse
 // filter runs afterwards, in place, k_iir_tiles).
+// qpad (kBlkCount): a window of nine zero bits is the waveform's padding only where padding can be -- inside its LAST payload
+// word (Qp <= qpad; 0 = that word is not in this block).  Anywhere else it is what a parse that is not yet in step sees inside
+// an escape's payload (z < 128 has nine leading zeros in its sixteen bits); a lane that stopped there reported a wrong END, its
+// successor restarted from that end and stopped there too, and the correction crept through the block one lane per settle
+// round: 256 rounds per block at m = 4 (25 % escapes), NOPTREX 26 ms instead of 2, 25 x 14 M samples 106 ms (round 3).
 template <int MODE, bool RESID = false>
 __device__ __forceinline__ void blk_parse(const uint32_t *W, uint32_t k, bool enable, uint32_t &Qp, uint32_t qlim,
-                                          uint32_t &c, uint32_t &sum, uint32_t cmax, uint16_t *outp, uint32_t *stage = nullptr) {
+                                          uint32_t &c, uint32_t &sum, uint32_t cmax, uint16_t *outp, uint32_t *stage = nullptr,
+                                          uint32_t qpad = 0u) {
     auto more = [&](uint32_t q, uint32_t cc) __attribute__((always_inline)) {
         return enable && (MODE == kBlkValue ? cc < cmax : (int32_t)(q - qlim) > 0);
     };
@@ -174,8 +183,8 @@ __device__ __forceinline__ void blk_parse(const uint32_t *W, uint32_t k, bool en
             const uint32_t Qa = Qp + p.nu1;
             bool act2 = act1 && more(Qa, c + 1u);
             if (MODE == kBlkCount) {
-                if (act1 && p.pad1) { act1 = act2 = false; qlim = Qp; }  // (Qp stays: where the padding starts)
-                if (act2 && p.pad2) { act2 = false; qlim = Qa; }
+                if (act1 && p.pad1 && (int32_t)(Qp - qpad) <= 0) { act1 = act2 = false; qlim = Qp; }  // (Qp stays: where the padding starts)
+                if (act2 && p.pad2 && (int32_t)(Qa - qpad) <= 0) { act2 = false; qlim = Qa; }
             }
             if (MODE != kBlkSkip) {
                 const uint32_t s1 = RESID ? unzigzag(p.z1) : sum + unzigzag(p.z1);
@@ -379,7 +388,9 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
             if (!active) Qp = C - B0;
             uint32_t f = C - Qp;  // first code that starts in my segment
             uint32_t *const my_stage = stage + tid * kBlkLaneStride;
-            blk_parse<kBlkCount, RESID>(W, k, active, Qp, C - lim, cnt, sum, 0u, nullptr, my_stage);
+            // where the waveform's zero padding can be: its last payload word, if this block holds it
+            const uint32_t qpad = (n - 1u >= w0 && n - 1u < w0 + BG::kWords) ? C - (B0 + 32u * (n - 1u - w0)) : 0u;
+            blk_parse<kBlkCount, RESID>(W, k, active, Qp, C - lim, cnt, sum, 0u, nullptr, my_stage, qpad);
             if (!active) { cnt = 0; sum = 0; }
             uint32_t e = C - Qp;  // first code that starts behind it (or where the padding starts)
             BLK_STAMP(2);  // run-up + count (thread 0's wave)
@@ -393,7 +404,7 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
                     const bool changed = active && want != f;
                     if (!wg_any(changed)) break;  // (also: every read of s_e is done before the next write)
                     if (changed) { f = want; Qp = C - f; cnt = 0; sum = 0; }
-                    blk_parse<kBlkCount, RESID>(W, k, changed, Qp, C - lim, cnt, sum, 0u, nullptr, my_stage);
+                    blk_parse<kBlkCount, RESID>(W, k, changed, Qp, C - lim, cnt, sum, 0u, nullptr, my_stage, qpad);
                     if (changed) e = C - Qp;
                 }
             };
@@ -421,7 +432,7 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
                 const bool fix0 = tid == 0 && true_f0 != f;
                 if (wg_any(fix0)) {
                     if (fix0) { f = true_f0; Qp = C - f; cnt = 0; sum = 0; }
-                    blk_parse<kBlkCount, RESID>(W, k, fix0, Qp, C - lim, cnt, sum, 0u, nullptr, my_stage);
+                    blk_parse<kBlkCount, RESID>(W, k, fix0, Qp, C - lim, cnt, sum, 0u, nullptr, my_stage, qpad);
                     if (fix0) e = C - Qp;
                     settle();
                     // a one-block run has published its end already, and its successor has started from it: if that end

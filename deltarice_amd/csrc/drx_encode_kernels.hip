@@ -303,7 +303,10 @@ __global__ __launch_bounds__(256) void k_encode_pack(Geom G, const int16_t *__re
 // re-encoded tile by tile straight to its final position (second read of its samples).
 // (the packed tile code: drx_encode.h)
 
-constexpr int kEncWaves = 8;  // waveforms (wavefronts) per workgroup = per ticket
+#ifndef DRX_ENC_WAVES
+#define DRX_ENC_WAVES 8
+#endif
+constexpr int kEncWaves = DRX_ENC_WAVES;  // waveforms (wavefronts) per workgroup = per ticket
 #ifndef DRX_ENC_LB_WIN
 #define DRX_ENC_LB_WIN 2
 #endif

@@ -62,7 +62,7 @@ def main():
         ragged = rng.random() < 0.25
         n_chunks = int(rng.integers(1, 6))
         taps = None
-        if not ragged and rng.random() < 0.2:
+        if rng.random() < 0.2:  # (ragged batches too: drx_plan_set_filter applies to every chunk)
             nt = int(rng.integers(1, 6))
             taps = [int(rng.choice([1, -1])) if rng.random() < 0.8 else int(rng.integers(2, 5))] + [int(v) for v in rng.integers(-3, 4, nt - 1)]
         if ragged:
@@ -83,18 +83,19 @@ def main():
         log(label)
         try:
             # oracle stream, chunk by chunk
-            words, offs = [], [0]
+            words, offs, copts = [], [0], []
             pos = 0
             for n, L in zip(Ns, Ls):
                 opts = (1 << k, L) + ((len(taps),) + tuple(t & 0xFFFFFFFF for t in taps) if taps else ())
                 w = O.encode_chunk(x[pos:pos + n], opts)
                 words.append(w)
+                copts.append(opts)
                 offs.append(offs[-1] + w.size)
                 pos += n
             ref_w = np.concatenate(words)
             ref_off = np.array(offs, np.uint64)
             if ragged:
-                plan = ctx.plan(Ns, Ls, 1 << k)
+                plan = ctx.plan(Ns, Ls, 1 << k, taps=taps)
             else:
                 opts = (1 << k, Ls[0]) + ((len(taps),) + tuple(t & 0xFFFFFFFF for t in taps) if taps else ())
                 plan = ctx.plan_uniform(n_chunks, Ns[0], opts)
@@ -114,7 +115,7 @@ def main():
             lossless = taps is None or abs(taps[0]) == 1
             expect = x
             if not lossless:
-                expect = np.concatenate([O.decode_chunk(ww, opts) for ww in words])
+                expect = np.concatenate([O.decode_chunk(ww, oo) for ww, oo in zip(words, copts)])
             for flags, impl in ((0, 8), (256, 8), (512, 8), (0, 7), (256, 7), (0, 0), (131072, 8)):
                 ctx.set_option("debug_flags", flags)
                 ctx.set_option("decode_impl", impl)
@@ -123,6 +124,13 @@ def main():
                 assert np.array_equal(y, expect), f"decode (flags {flags}, impl {impl})"
             ctx.set_option("debug_flags", 0)
             ctx.set_option("decode_impl", 8)
+            # the encoder's n_i table as a side-band (drx_decode_with_wave_words)
+            log("  side-band decode")
+            plan.encode(xd)
+            table = plan.wave_words_device()
+            y = plan.decode_with_wave_words(enc.words, enc.chunk_word_off, table, in_words=enc.total_words)
+            plan.finish()
+            assert np.array_equal(y.cpu().numpy(), expect), "side-band decode"
             # the one-chunk host path (what the H5Z callback runs) on the first chunk
             opts0 = (1 << k, Ls[0]) + ((len(taps),) + tuple(t & 0xFFFFFFFF for t in taps) if taps else ())
             log("  host path")

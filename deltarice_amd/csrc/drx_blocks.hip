@@ -117,8 +117,9 @@ enum { kBlkSkip = 0, kBlkCount = 1, kBlkValue = 2 };
 #define BLK_STAMP(i) do { } while (0)
 #endif
 
-// count-leading-zeros that is defined for 0 (any value will do there: an all-zero window exists only in a corrupt stream)
-__device__ __forceinline__ uint32_t clz_nz(uint32_t x) { return (uint32_t)__builtin_clz(x | 1u); }
+// count-leading-zeros that is defined for 0: v_ffbh_u32 returns -1 there, which with the escape's 16 payload bits moves the
+// parse on by 15 + 1 bits -- any progress will do (an all-zero window is the padding behind a waveform or a corrupt stream)
+__device__ __forceinline__ uint32_t clz_nz(uint32_t x) { return ffbh(x); }
 
 // Two codes from the 64-bit window at Qp (three words: a 64-bit window always holds two codes of at most 25 bits).
 // W: the block's LDS image; word w of the image sits at W[K + 1 - w] and Qp = 32 K - (bit position), so that
@@ -168,13 +169,16 @@ __device__ __forceinline__ uint32_t unzigzag(uint32_t z) { return (z >> 1) ^ (0u
 // an escape's payload (z < 128 has nine leading zeros in its sixteen bits); a lane that stopped there reported a wrong END, its
 // successor restarted from that end and stopped there too, and the correction crept through the block one lane per settle
 // round: 256 rounds per block at m = 4 (25 % escapes), NOPTREX 26 ms instead of 2, 25 x 14 M samples 106 ms (round 3).
-template <int MODE, bool RESID = false>
+// PAD = false: the caller knows that qpad = 0 (every block but a waveform's last), and the padding test is compiled away.
+template <int MODE, bool RESID = false, bool PAD = true>
 __device__ __forceinline__ void blk_parse(const uint32_t *W, uint32_t k, bool enable, uint32_t &Qp, uint32_t qlim,
                                           uint32_t &c, uint32_t &sum, uint32_t cmax, uint16_t *outp, uint32_t *stage = nullptr,
                                           uint32_t qpad = 0u) {
     auto more = [&](uint32_t q, uint32_t cc) __attribute__((always_inline)) {
         return enable && (MODE == kBlkValue ? cc < cmax : (int32_t)(q - qlim) > 0);
     };
+    // staging slot of the next pair (kBlkCount; c is even whenever a pair is staged): a dword index that saturates at the dump slot
+    uint32_t slot = (c >> 1) < kBlkLaneCap / 2u ? (c >> 1) : kBlkLaneCap / 2u;
     while (__any(more(Qp, c))) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {  // one vote per four codes
@@ -182,7 +186,7 @@ __device__ __forceinline__ void blk_parse(const uint32_t *W, uint32_t k, bool en
             bool act1 = more(Qp, c);
             const uint32_t Qa = Qp + p.nu1;
             bool act2 = act1 && more(Qa, c + 1u);
-            if (MODE == kBlkCount) {
+            if (MODE == kBlkCount && PAD) {
                 if (act1 && p.pad1 && (int32_t)(Qp - qpad) <= 0) { act1 = act2 = false; qlim = Qp; }  // (Qp stays: where the padding starts)
                 if (act2 && p.pad2 && (int32_t)(Qa - qpad) <= 0) { act2 = false; qlim = Qa; }
             }
@@ -194,8 +198,8 @@ __device__ __forceinline__ void blk_parse(const uint32_t *W, uint32_t k, bool en
                     if (act2) outp[c + 1u] = (uint16_t)s2;
                 }
                 if (MODE == kBlkCount) {  // c is even here: only a lane's last pair can end after its first code
-                    const uint32_t slot = (c >> 1) < kBlkLaneCap / 2u ? (c >> 1) : kBlkLaneCap / 2u;
                     if (act1) stage[slot] = __builtin_amdgcn_perm(s2, s1, 0x05040100u);
+                    slot = slot + 1u < kBlkLaneCap / 2u ? slot + 1u : kBlkLaneCap / 2u;
                 }
                 sum = act2 ? s2 : (act1 ? s1 : sum);
             }
@@ -390,7 +394,8 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
             uint32_t *const my_stage = stage + tid * kBlkLaneStride;
             // where the waveform's zero padding can be: its last payload word, if this block holds it
             const uint32_t qpad = (n - 1u >= w0 && n - 1u < w0 + BG::kWords) ? C - (B0 + 32u * (n - 1u - w0)) : 0u;
-            blk_parse<kBlkCount, RESID>(W, k, active, Qp, C - lim, cnt, sum, 0u, nullptr, my_stage, qpad);
+            if (qpad) blk_parse<kBlkCount, RESID, true>(W, k, active, Qp, C - lim, cnt, sum, 0u, nullptr, my_stage, qpad);
+            else blk_parse<kBlkCount, RESID, false>(W, k, active, Qp, C - lim, cnt, sum, 0u, nullptr, my_stage, 0u);
             if (!active) { cnt = 0; sum = 0; }
             uint32_t e = C - Qp;  // first code that starts behind it (or where the padding starts)
             BLK_STAMP(2);  // run-up + count (thread 0's wave)
@@ -567,15 +572,22 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
             if (!wg_any(!lane_ok)) {
                 constexpr int NR = (int)(kBlkLaneCap / 2u);
                 uint32_t rr[NR];
+                // (pairs beyond the wavefront's largest count are skipped by a scalar branch: 54 of the 76 slots are used on average)
+                const uint32_t wmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(cnt));
 #pragma unroll
-                for (int i = 0; i < NR; ++i) rr[i] = my_stage[i];
+                for (int i = 0; i < NR; ++i) {
+                    rr[i] = 0;
+                    if (2u * (uint32_t)i < wmax) rr[i] = my_stage[i];
+                }
                 blk_barrier();  // every lane holds its samples: the buffer may now be rewritten in output order
                 const uint32_t base16 = RESID ? 0u : (acc_base + pre_s + incl_s - sum) & 0xffffu;  // the running sum in front of my first sample
                 const uint32_t slot0 = a0 + rel0, dump = 2u * BG::kStageWords - 1u;  // (the last halfword: beyond a0 + kOutCap)
 #pragma unroll
                 for (int i = 0; i < NR; ++i) {
-                    obuf[(2u * (uint32_t)i < cnt) ? slot0 + 2u * (uint32_t)i : dump] = (uint16_t)(rr[i] + base16);
-                    obuf[(2u * (uint32_t)i + 1u < cnt) ? slot0 + 2u * (uint32_t)i + 1u : dump] = (uint16_t)((rr[i] >> 16) + base16);
+                    if (2u * (uint32_t)i < wmax) {
+                        obuf[(2u * (uint32_t)i < cnt) ? slot0 + 2u * (uint32_t)i : dump] = (uint16_t)(rr[i] + base16);
+                        obuf[(2u * (uint32_t)i + 1u < cnt) ? slot0 + 2u * (uint32_t)i + 1u : dump] = (uint16_t)((rr[i] >> 16) + base16);
+                    }
                 }
                 blk_barrier();
                 BLK_STAMP(6);  // reorder

@@ -10,10 +10,12 @@
 // (c_j = -+taps[j], d' = +-d), so a run of samples maps its incoming state to its outgoing state by an AFFINE map whose
 // matrix depends only on the run's LENGTH.  The block-parallel decoder (drx_blocks.hip, RESID) therefore leaves the residuals
 // themselves in the output buffer, and this kernel turns them into samples:
-//   tile      a workgroup of 1024 lanes x 32 consecutive samples = 32 768 samples of one waveform, tiles in ticket order (one
-//             global ticket counter serves ~88 workgroups per microsecond: 8192-sample tiles ran at exactly that rate);
-//   pass 1    every lane runs the recurrence over its 32 residuals from a ZERO state: the zero-state response's final state;
-//   scan      Hillis-Steele over the lanes of a wavefront with the matrices A^(32 o), o = 1, 2, 4 ... 32 (all lanes of a
+//   tile      a workgroup of 512 lanes x 64 consecutive samples = 32 768 samples of one waveform, tiles in ticket order (one
+//             global ticket counter serves ~88 workgroups per microsecond: 8192- and 16 384-sample tiles ran at exactly that
+//             rate); two workgroups per CU, so that one's memory phases run under the other's arithmetic (1024 lanes x 32
+//             samples, one workgroup per CU: 0.9 ms for 671 M samples; 512 x 32: 0.72 ms; this form: see profiles/r03_notes.md);
+//   pass 1    every lane runs the recurrence over its M = 64 residuals from a ZERO state: the zero-state response's final state;
+//   scan      Hillis-Steele over the lanes of a wavefront with the matrices A^(M o), o = 1, 2, 4 ... 32 (all lanes of a
 //             step use the same matrix: equal run lengths), then over the sixteen wavefronts: the state in front of every lane
 //             given a zero state in front of the tile, and the tile's own zero-state response B;
 //   look-back the state in front of the tile: x = B_{t-1} + P B_{t-2} + P^2 B_{t-3} + ... (P = A^32768) down to the nearest
@@ -31,7 +33,7 @@
 
 namespace drx {
 
-// table layout (uint32 each): PL[7][9] = A^(32 * 2^d), d = 0..6 | PLANE[64][9] = A^(32 l) | PTP[kIirWin + 1][9] = P^j | c1 c2 c3 sgn
+// table layout (uint32 each): PL[7][9] = A^(M * 2^d), d = 0..6 | PLANE[64][9] = A^(M l) | PTP[kIirWin + 1][9] = P^j | c1 c2 c3 sgn
 constexpr uint32_t kIirPL = 0, kIirPLANE = 7 * 9, kIirPTP = kIirPLANE + 64 * 9, kIirC = kIirPTP + (kIirWin + 1) * 9;
 static_assert(kIirC + 4 == kIirTabWords, "table layout");
 
@@ -109,6 +111,14 @@ __global__ __launch_bounds__(kIirThreads) void k_iir_tiles(Geom G, const uint64_
                                                            uint32_t *__restrict__ ticket, const uint32_t *__restrict__ skip,
                                                            DevStatus *st, int16_t *__restrict__ out) {
     constexpr int M = kIirRun, NWV = kIirThreads / 64;
+    // A lane owns M consecutive samples (2 M bytes), so lane-private loads would touch 64 different lines per instruction.
+    // A tile that lies wholly inside its waveform therefore moves through LDS: every wavefront loads its 128 M contiguous
+    // bytes in 1 KB instructions (16-byte piece p to lane p mod 64), writes the pieces to rows of kRowB bytes (a lane's
+    // 2 M bytes + 16 of padding: with a row stride of 36 / 68 banks both the linear writes and the row-wise 16-byte reads
+    // are free of bank conflicts), and every lane reads its own row; the samples go back the same way.
+    constexpr int NP = M / 8;                      // 16-byte pieces per lane
+    constexpr uint32_t kRowB = 2u * M + 16u;       // bytes per row
+    __shared__ __attribute__((aligned(16))) uint8_t s_t[NWV][64 * kRowB];
     __shared__ uint32_t s_u;
     __shared__ uint32_t s_F[NWV][3], s_x[3];
     const uint32_t tid = threadIdx.x;
@@ -122,14 +132,33 @@ __global__ __launch_bounds__(kIirThreads) void k_iir_tiles(Geom G, const uint64_
     int16_t *y = out + r.sample_off;
     const uint32_t c1 = tab[kIirC], c2 = tab[kIirC + 1], c3 = tab[kIirC + 2], sg = tab[kIirC + 3];
 
-    // ---- my 32 residuals, two per dword ----
+    // ---- my M residuals, two per dword ----
     const uint32_t i0 = q.t * kIirTile + tid * (uint32_t)M;
     const uint32_t nv = i0 >= r.len ? 0u : (r.len - i0 < (uint32_t)M ? r.len - i0 : (uint32_t)M);
     uint32_t d[M / 2];
-    if (nv == (uint32_t)M) {
+    const bool whole = (uint64_t)(q.t + 1u) * kIirTile <= (uint64_t)r.len;  // (uniform over the workgroup)
+    int16_t *const wbase = y + (q.t * kIirTile + (uint32_t)wv * 64u * (uint32_t)M);  // my wavefront's 64 M samples
+    uint8_t *const rows = s_t[wv];
+    if (whole) {
+        uint4 v[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) v[j] = *reinterpret_cast<const uint4 *>(wbase + 8 * (j * 64 + lane));  // (any int16 alignment: unaligned access is on)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const uint32_t p = (uint32_t)(j * 64 + lane);
+            *reinterpret_cast<uint4 *>(rows + (p / NP) * kRowB + (p % NP) * 16u) = v[j];
+        }
+        wave_sync();
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const uint4 w = *reinterpret_cast<const uint4 *>(rows + (uint32_t)lane * kRowB + 16u * j);
+            d[4 * j] = w.x; d[4 * j + 1] = w.y; d[4 * j + 2] = w.z; d[4 * j + 3] = w.w;
+        }
+        wave_sync();
+    } else if (nv == (uint32_t)M) {
 #pragma unroll
         for (int j = 0; j < M / 8; ++j) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(y + i0 + 8 * j);  // (any int16 alignment: unaligned access is on)
+            const uint4 v = *reinterpret_cast<const uint4 *>(y + i0 + 8 * j);
             d[4 * j] = v.x; d[4 * j + 1] = v.y; d[4 * j + 2] = v.z; d[4 * j + 3] = v.w;
         }
     } else {
@@ -157,7 +186,7 @@ __global__ __launch_bounds__(kIirThreads) void k_iir_tiles(Geom G, const uint64_
     V3 F = lo16(run(V3{0u, 0u, 0u}, std::false_type{}));
 #pragma unroll
     for (int dd = 0; dd < 6; ++dd) {
-        const M3 P = load_m3(tab + kIirPL + 9 * dd);  // A^(32 * 2^dd)
+        const M3 P = load_m3(tab + kIirPL + 9 * dd);  // A^(M * 2^dd)
         const V3 up = shfl_up_v3(F, 1 << dd);
         if (lane >= (1 << dd)) F = lo16(add(F, mul(P, up)));
     }
@@ -165,7 +194,7 @@ __global__ __launch_bounds__(kIirThreads) void k_iir_tiles(Geom G, const uint64_
     if (lane == 0) E = V3{0u, 0u, 0u};
     if (lane == 63) { s_F[wv][0] = F.x; s_F[wv][1] = F.y; s_F[wv][2] = F.z; }
     __syncthreads();
-    const M3 PW = load_m3(tab + kIirPL + 9 * 6);  // A^(32 * 64): one wavefront
+    const M3 PW = load_m3(tab + kIirPL + 9 * 6);  // A^(M * 64): one wavefront
     if (wv == 0) {
         // the tile's zero-state response B, then the state in front of the tile
         V3 B{0u, 0u, 0u};
@@ -234,7 +263,18 @@ __global__ __launch_bounds__(kIirThreads) void k_iir_tiles(Geom G, const uint64_
     for (int w = 0; w < wv; ++w) XW = lo16(add(mul(PW, XW), V3{s_F[w][0], s_F[w][1], s_F[w][2]}));
     const V3 S = lo16(add(mul(load_m3(tab + kIirPLANE + 9 * lane), XW), E));
     (void)run(S, std::true_type{});
-    if (nv == (uint32_t)M) {
+    if (whole) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+            *reinterpret_cast<uint4 *>(rows + (uint32_t)lane * kRowB + 16u * j) = make_uint4(d[4 * j], d[4 * j + 1], d[4 * j + 2], d[4 * j + 3]);
+        wave_sync();
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const uint32_t p = (uint32_t)(j * 64 + lane);
+            const uint4 w = *reinterpret_cast<const uint4 *>(rows + (p / NP) * kRowB + (p % NP) * 16u);
+            *reinterpret_cast<uint4 *>(wbase + 8 * p) = w;
+        }
+    } else if (nv == (uint32_t)M) {
 #pragma unroll
         for (int j = 0; j < M / 8; ++j)
             *reinterpret_cast<uint4 *>(y + i0 + 8 * j) = make_uint4(d[4 * j], d[4 * j + 1], d[4 * j + 2], d[4 * j + 3]);
@@ -262,21 +302,21 @@ void iir_tables(const uint32_t fast_nt[3], uint32_t t0neg, uint32_t *tab) {
     const uint32_t sg = t0neg ? 0xffffu : 1u;
     const uint32_t c[3] = {(fast_nt[0] * sg) & 0xffffu, (fast_nt[1] * sg) & 0xffffu, (fast_nt[2] * sg) & 0xffffu};
     Mat A = {c[0], c[1], c[2], 1, 0, 0, 0, 1, 0}, I = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    Mat P;  // A^32: one lane's run
+    Mat P;  // A^M: one lane's run
     for (int i = 0; i < 9; ++i) P[i] = I[i];
     for (uint32_t i = 0; i < kIirRun; ++i) mmul(A, P, P);
     Mat cur;
     for (int i = 0; i < 9; ++i) cur[i] = P[i];
-    for (int d = 0; d < 7; ++d) {  // A^(32 * 2^d)
+    for (int d = 0; d < 7; ++d) {  // A^(M * 2^d)
         for (int i = 0; i < 9; ++i) tab[kIirPL + 9 * d + i] = cur[i];
         mmul(cur, cur, cur);
     }
     for (int i = 0; i < 9; ++i) cur[i] = I[i];
-    for (int l = 0; l < 64; ++l) {  // A^(32 l)
+    for (int l = 0; l < 64; ++l) {  // A^(M l)
         for (int i = 0; i < 9; ++i) tab[kIirPLANE + 9 * l + i] = cur[i];
         mmul(P, cur, cur);
     }
-    Mat PT;  // A^32768 = (A^(32 * 64))^(threads / 64)
+    Mat PT;  // A^tile = (A^(M * 64))^(threads / 64)
     for (int i = 0; i < 9; ++i) PT[i] = I[i];
     for (uint32_t w = 0; w < kIirThreads / 64u; ++w) mmul(tab + kIirPL + 9 * 6, PT, PT);
     for (int i = 0; i < 9; ++i) cur[i] = I[i];

@@ -216,7 +216,13 @@ hipError_t launch_encode_pieces(const Geom &G, const int16_t *d_in, uint64_t in_
                                 DevStatus *d_status, hipEvent_t *ev, hipStream_t s);
 // in-place inverse of a general prediction filter over decoded residuals (drx_iir.hip): tiles of kIirThreads lanes x kIirRun
 // samples, decoupled look-back over kIirWin tiles per poll, tables of kIirTabWords uint32 per filter
-constexpr uint32_t kIirRun = 32, kIirThreads = 1024, kIirTile = kIirRun * kIirThreads, kIirWin = 128;
+#ifndef DRX_IIR_THREADS
+#define DRX_IIR_THREADS 512
+#endif
+#ifndef DRX_IIR_RUN
+#define DRX_IIR_RUN 64
+#endif
+constexpr uint32_t kIirRun = DRX_IIR_RUN, kIirThreads = DRX_IIR_THREADS, kIirTile = kIirRun * kIirThreads, kIirWin = 128;
 constexpr uint32_t kIirTabWords = (7 + 64 + (kIirWin + 1)) * 9 + 4;
 void iir_tables(const uint32_t fast_nt[3], uint32_t t0neg, uint32_t *tab);
 uint64_t iir_tiles(const Geom &G, const ChunkDesc *host_chunks, uint64_t *chunk_tile_base);  // (chunk_tile_base: n_chunks + 1, ragged only)

@@ -41,7 +41,10 @@ def test_general_filter_few_long_waveforms_uniform(ctx, O):
     rng = np.random.default_rng(301)
     shapes = [(2, 5, 60000, 3, "gauss10"), (1, 32, 81920, 3, "gauss10"), (2, 4, 30011, 8, "gauss300"), (1, 6, 9000, 3, "uniform"),
               (3, 1, 150000, 3, "steps"), (1, 3, 8193, 3, "gauss10"), (1, 2, 8192, 3, "gauss10"), (1, 3, 24577, 3, "gauss10"),
-              (1, 7, 4097, 15, "uniform"), (1, 2, 2500000, 3, "gauss10")]  # (the last: 306 tiles per waveform, three look-back windows)
+              (1, 7, 4097, 15, "uniform"), (1, 2, 2500000, 3, "gauss10"),  # (77 tiles per waveform)
+              # whole tiles (32 768 samples: moved through LDS) at an odd sample offset, a waveform of whole tiles only, a
+              # last tile that ends inside its first / behind its seventh wavefront
+              (1, 3, 40001, 3, "gauss10"), (2, 2, 65536, 3, "gauss10"), (1, 2, 32768 + 100, 3, "gauss10"), (1, 2, 32768 + 7 * 4096 + 5, 3, "gauss300")]
     for si, (n_chunks, W, L, k, kind) in enumerate(shapes):
         N = W * L - (L // 3 if W > 2 else 0)  # a shorter last waveform where there is room for one
         x = make_data(rng, kind, n_chunks * N)

@@ -179,7 +179,7 @@ __device__ __forceinline__ void blk_parse(const uint32_t *W, uint32_t k, bool en
     };
     // staging slot of the next pair (kBlkCount; c is even whenever a pair is staged): a dword index that saturates at the dump slot
     uint32_t slot = (c >> 1) < kBlkLaneCap / 2u ? (c >> 1) : kBlkLaneCap / 2u;
-    while (__any(more(Qp, c))) {
+    while (__builtin_amdgcn_ballot_w64(more(Qp, c)) != 0ull) {  // (__any() costs a v_cndmask and a v_cmp more)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {  // one vote per four codes
             const BlkPair p = blk_pair<MODE != kBlkSkip>(W, k, Qp);
@@ -581,12 +581,17 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
                 }
                 blk_barrier();  // every lane holds its samples: the buffer may now be rewritten in output order
                 const uint32_t base16 = RESID ? 0u : (acc_base + pre_s + incl_s - sum) & 0xffffu;  // the running sum in front of my first sample
-                const uint32_t slot0 = a0 + rel0, dump = 2u * BG::kStageWords - 1u;  // (the last halfword: beyond a0 + kOutCap)
+                // both halves of a dword take the base in one packed add; the two 16-bit stores have immediate offsets from one
+                // address and are masked by the lane's count (an exec mask costs a compare, a dump slot a compare and a select)
+                typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+                const u16x2 b2 = {(uint16_t)base16, (uint16_t)base16};
+                uint16_t *const op = obuf + (a0 + rel0);
 #pragma unroll
                 for (int i = 0; i < NR; ++i) {
                     if (2u * (uint32_t)i < wmax) {
-                        obuf[(2u * (uint32_t)i < cnt) ? slot0 + 2u * (uint32_t)i : dump] = (uint16_t)(rr[i] + base16);
-                        obuf[(2u * (uint32_t)i + 1u < cnt) ? slot0 + 2u * (uint32_t)i + 1u : dump] = (uint16_t)((rr[i] >> 16) + base16);
+                        const u16x2 v = __builtin_bit_cast(u16x2, rr[i]) + b2;
+                        if (2u * (uint32_t)i < cnt) op[2 * i] = v.x;
+                        if (2u * (uint32_t)i + 1u < cnt) op[2 * i + 1] = v.y;
                     }
                 }
                 blk_barrier();

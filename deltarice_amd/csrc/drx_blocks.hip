@@ -554,17 +554,20 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
             auto copy_out = [&](uint32_t R0) __attribute__((always_inline)) {  // staged samples [R0, R0 + kOutCap) of the block -> HBM
                 const uint32_t nsamp = (blk_count - R0 < BG::kOutCap) ? blk_count - R0 : BG::kOutCap;
                 g_u16 *gbase = (g_u16 *)(y + blk_first + R0) - a0;  // 16-byte aligned
-                const uint32_t np = (a0 + nsamp + 7u) >> 3;
-                for (uint32_t p = tid; p < np; p += NT) {
-                    const uint32_t s_lo = 8u * p;
-                    if (s_lo >= a0 && s_lo + 8u <= a0 + nsamp) {
-                        const uint4 v = *reinterpret_cast<const uint4 *>(obuf + s_lo);
-                        *(g_uint4 *)(gbase + s_lo) = (u32x4v){v.x, v.y, v.z, v.w};
-                    } else {
-#pragma unroll
-                        for (uint32_t j = 0; j < 8u; ++j)
-                            if (s_lo + j >= a0 && s_lo + j < a0 + nsamp) gbase[s_lo + j] = obuf[s_lo + j];
-                    }
+                // whole 16-byte pieces [p_lo, p_hi) without a test per piece; the up to seven samples in front of the first and
+                // behind the last one by sixteen lanes
+                const uint32_t end = a0 + nsamp, p_lo = (a0 + 7u) >> 3, p_hi = end >> 3;
+                auto piece = [&](uint32_t p) __attribute__((always_inline)) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(obuf + 8u * p);
+                    *(g_uint4 *)(gbase + 8u * p) = (u32x4v){v.x, v.y, v.z, v.w};
+                };
+                uint32_t p = tid;  // (piece p by thread p mod NT: a wavefront's store instruction covers whole aligned lines)
+                if (p >= p_lo && p < p_hi) piece(p);
+                for (p += NT; p < p_hi; p += NT) piece(p);
+                if (tid < 16u) {
+                    const uint32_t s = tid < 8u ? tid : 8u * p_hi + (tid - 8u);
+                    const bool ok = tid < 8u ? (s >= a0 && s < 8u * p_lo && s < end) : (p_hi >= p_lo && s >= a0 && s < end);
+                    if (ok) gbase[s] = obuf[s];
                 }
             };
             // the common case: every lane's codes are all samples of the waveform and fit its share of the staging buffer

@@ -240,6 +240,24 @@ __device__ __forceinline__ void blk_count_pairs(const uint32_t *W, uint32_t k, b
     if (enable && c != 0u && !(Qa_l > qlim)) { c -= 1u; Qp = Qa_l; sum = s1_l; }
 }
 
+// The run-up in the same form: codes are skipped, a pair at a time, while they start in front of the limit.
+__device__ __forceinline__ void blk_skip_pairs(const uint32_t *W, uint32_t k, bool enable, uint32_t &Qp, uint32_t qlim) {
+    uint32_t Qa_l = Qp;
+    bool act = enable && Qp > qlim;
+    while (__builtin_amdgcn_ballot_w64(act) != 0ull) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (act) {
+                const BlkPair p = blk_pair<false>(W, k, Qp);
+                Qa_l = Qp + p.nu1;
+                Qp = Qa_l + p.nu2;
+            }
+            act = act && Qp > qlim;
+        }
+    }
+    if (enable && !(Qa_l > qlim)) Qp = Qa_l;  // (no pair taken: Qa_l is Qp)
+}
+
 template <int NT, bool RESID = false>
 __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
                                                       const uint64_t *__restrict__ wave_off,
@@ -267,7 +285,8 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
     uint32_t &s_unit = s_e[NT + 2 * NW + 4], &s_pred = s_e[NT + 2 * NW + 5];
     const uint32_t tid = threadIdx.x;
     const int lane = lane_id(), wv = (int)(tid >> 6);
-    const uint32_t k = G.k;
+    uint32_t k = G.k;
+    asm volatile("" : "+v"(k));  // in a VGPR for good: the parse selects between k and 16 per code, and re-materialised it per pair
     // A ticket is a RUN of run_len consecutive blocks of one waveform, dealt run-major: run 0 of every waveform, then run 1
     // of every waveform, ...  Inside a run only its first block talks to other workgroups (where the predecessor's
     // stream ended, the look-back for samples and sum in front of it); the others start exactly where the block before
@@ -418,8 +437,8 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
             const bool exact0 = tid == 0 && (blk == 0 || !first_of_run);
             const uint32_t start0 = B0 + (first_of_run ? 0u : carry_rel);
             uint32_t Qp = C - (exact0 ? start0 : (active ? bj - kBlkGuessBits : B0));
-            uint32_t cnt = 0, sum = 0, dummy_c = 0, dummy_s = 0;
-            blk_parse<kBlkSkip>(W, k, active && !exact0, Qp, C - bj, dummy_c, dummy_s, 0u, nullptr);
+            uint32_t cnt = 0, sum = 0;
+            blk_skip_pairs(W, k, active && !exact0, Qp, C - bj);
             if (!active) Qp = C - B0;
             uint32_t f = C - Qp;  // first code that starts in my segment
             uint32_t *const my_stage = stage + tid * kBlkLaneStride;

@@ -53,7 +53,10 @@ constexpr uint32_t kBlkPre = 8;          // words kept in front of a block: lane
 #endif
 constexpr uint32_t kBlkGuessBits = DRX_BLK_GUESS_BITS;  // run-up in front of a segment (a parse is in step after a few codes; 96, 128,
                                          // 160 and 224 bits measured: within 4 % of one another, profiles/r02_notes.md)
-constexpr uint32_t kBlkRun = 4;          // consecutive blocks of a waveform per ticket, when waveforms outnumber workgroups
+#ifndef DRX_BLK_ROUNDS
+#define DRX_BLK_ROUNDS 8
+#endif
+constexpr uint32_t kBlkRounds = DRX_BLK_ROUNDS;  // tickets per resident workgroup a launch should at least have (see run_len)
 constexpr uint32_t kBlkTail = 4;         // words behind a block: a code that starts inside may end 24 bits behind it,
                                          // and a window reads three words
 
@@ -804,12 +807,20 @@ hipError_t launch_decode_blocks(const Geom &G, const uint32_t *d_in, uint64_t in
     if (e != hipSuccess) return e;
     // resident grid: 256 CUs x workgroups per CU (LDS: 51 KB at NT = 256, 26 KB at 128, 13 KB at 64), never more than there are units
     const uint32_t spw = blocks_slots_per_wave(G);
-    auto launch_class = [&](uint32_t cls, const uint32_t *list, uint32_t n_waves, int nt) {
+    auto launch_class = [&](uint32_t cls, const uint32_t *list, uint32_t n_waves, int nt, uint32_t wave_len) {
         uint32_t *info = L.info + 4u * cls;
         k_blk_max<<<1, 1024, 0, s>>>(n_waves, d_wave_words, blk_words((uint32_t)nt), info, list);
         const uint64_t units = (uint64_t)n_waves * spw;
-        // runs of several blocks only when two runs of one waveform are never in flight together (see the kernel)
-        const uint32_t run_len = n_waves >= 768u ? kBlkRun : 1u;
+        // Runs of several blocks only when two runs of one waveform are never in flight together (see the kernel): at least
+        // as many waveforms as resident workgroups.  Then as long as the launch keeps kBlkRounds tickets per workgroup (the
+        // tail of the last round), up to the whole waveform: only a run's first block waits for other workgroups (nEDM, 6
+        // blocks per waveform: one run; NOPTREX, 36: three runs of 12: 1.40 / 0.98 ms against 1.43 / 1.00 with round 2's fixed 4).
+        const uint32_t resident = 256u * (nt == 64 ? 12u : (nt == 128 ? 6u : 3u));
+        const uint64_t typ_words = ((uint64_t)wave_len * (2u * G.k + 7u)) >> 6;
+        const uint64_t bpw = (typ_words + blk_words((uint32_t)nt) - 1u) / blk_words((uint32_t)nt);
+        uint64_t rl = ((uint64_t)n_waves * bpw) / ((uint64_t)kBlkRounds * resident);
+        rl = rl > bpw ? bpw : rl;
+        const uint32_t run_len = n_waves >= resident ? (uint32_t)(rl < 1u ? 1u : rl) : 1u;
         auto go = [&](auto nt_tag, auto resid_tag, unsigned per_cu) {
             constexpr int NT = decltype(nt_tag)::value;
             constexpr bool RESID = decltype(resid_tag)::value;
@@ -822,11 +833,11 @@ hipError_t launch_decode_blocks(const Geom &G, const uint32_t *d_in, uint64_t in
         else { if (resid) go(std::integral_constant<int, 256>{}, std::true_type{}, 3u); else go(std::integral_constant<int, 256>{}, std::false_type{}, 3u); }
     };
     if (G.uniform) {
-        launch_class(0u, nullptr, (uint32_t)G.total_waves, blocks_nt(G));
+        launch_class(0u, nullptr, (uint32_t)G.total_waves, blocks_nt(G), G.u_wave_len);
     } else {
         for (uint32_t c = 0; c < G.rag_blk_classes; ++c)
             launch_class(c, G.rag_blk_list + G.rag_blk_class_off[c], G.rag_blk_class_off[c + 1] - G.rag_blk_class_off[c],
-                         nt_for_len(G.rag_blk_class_len[c], G.k));
+                         nt_for_len(G.rag_blk_class_len[c], G.k), G.rag_blk_class_len[c]);
     }
 #ifdef DRX_BLK_STAMPS
     {

@@ -317,7 +317,7 @@ static drx_status plan_alloc_scratch(drx_ctx *ctx, drx_plan *p) {
     }
     if (p->G.uniform) {  // the pieces encoder's workgroups, where the geometry is one it can take (pieces_batch() decides per call)
         const uint32_t L = p->G.u_wave_len;
-        const PieceShape sh = piece_shape(L, p->G.u_n_waves, piece_packable(L));
+        const PieceShape sh = piece_shape(L, p->G.u_n_waves, p->G.k, piece_packable(L));
         const uint64_t wgs = (uint64_t)sh.wgs * p->G.n_chunks;
         if ((L >= kPcMinLen || piece_packable(L)) && (uint64_t)p->G.u_n_waves * sh.parts <= 0x7fffffffull && wgs <= 0x7fffffffull && p->total_samples >= 512u)
             p->pc_wgs = wgs;
@@ -449,7 +449,7 @@ drx_status drx_plan_create(drx_ctx *ctx, uint64_t n_chunks, const uint32_t *chun
             std::vector<uint32_t> wb(n_chunks + 1, 0);
             uint64_t wgs = 0;
             for (uint64_t c = 0; c < n_chunks && ok; ++c) {
-                const PieceShape sh = piece_shape(desc[c].wave_len, desc[c].n_waves, all_packed);
+                const PieceShape sh = piece_shape(desc[c].wave_len, desc[c].n_waves, p->G.k, all_packed);
                 ok = (all_packed || desc[c].wave_len >= kPcMinLen) && (uint64_t)desc[c].n_waves * sh.parts <= 0x7fffffffull;
                 all_super = all_super && sh.parts > 1u;
                 none_super = none_super && sh.parts == 1u;

@@ -158,7 +158,22 @@ constexpr uint32_t kPcRunSamples = 7168;  // samples of a run of short waveforms
 constexpr uint32_t kPcMaxRun = 16;        // waveforms of a run
 constexpr uint32_t kPcSegSamples = 8192;  // most samples of a segment
 constexpr uint32_t kPcWholeLen = 10240;   // WaveformLengths up to here stay whole (6.4 bits per sample fit the buffer)
-constexpr uint32_t kPcMinLen = 64, kPcMaxLen = kPcSegSamples * kPcWaves;  // WaveformLengths it takes
+constexpr uint32_t kPcMinLen = 64;        // WaveformLengths it takes: from here
+// A piece's code must fit its wavefront's 2048-word LDS buffer, or the piece is coded a second time, tile by tile, straight
+// to its place (6 x slower: NOPTREX at sigma = 40, m = 32 -- 8.5 bits per sample -- encoded in 5.7 ms instead of 0.93; the
+// headline shape at sigma = 80, m = 64 in 2.2 ms per 100 chunks instead of 1.25).  With the RiceParameter that suits the data a
+// sample takes about k + 3.5 bits, so the pieces are sized for k + 4.5: the constants above are the measured geometry for
+// k <= 3 (m <= 8), beyond that a segment holds 131072 / (2 k + 9) samples in whole tiles.
+__host__ __device__ inline uint32_t pc_seg_samples(uint32_t k) {
+    if (k <= 3u) return kPcSegSamples;
+    const uint32_t s = (131072u / (2u * k + 9u)) & ~511u;
+    return s < 512u ? 512u : s;
+}
+__host__ __device__ inline uint32_t pc_run_samples(uint32_t k) { return k <= 3u ? kPcRunSamples : pc_seg_samples(k) - 512u; }
+// a waveform stays whole (one wavefront, and k_encode_fused's range stays k_encode_fused's) while it fits at k + 4 bits per
+// sample: two segments of 3500 samples cost a quarter of the rate (100 chunks of 2000 x 7000, sigma = 40, m = 32: 1.84 against 1.26 ms)
+__host__ __device__ inline uint32_t pc_whole_len(uint32_t k) { return k <= 3u ? kPcWholeLen : 65536u / (k + 4u); }
+__host__ __device__ inline uint32_t pc_max_len(uint32_t k) { return pc_seg_samples(k) * kPcWaves; }  // beyond: several workgroups per waveform
 struct PieceShape {
     uint32_t run;      // waveforms per piece (> 1: runs of short waveforms)
     uint32_t segs;     // pieces per waveform and workgroup (a power of two <= kPcWaves; > 1: long waveforms)
@@ -170,25 +185,29 @@ struct PieceShape {
 // waveforms of fewer than 512 samples, a multiple of 8 (a lane's 8 samples never straddle two waveforms): PACKED runs, whose
 // tiles span waveform boundaries
 __host__ __device__ inline bool piece_packable(uint32_t L) { return L >= 8u && L < 512u && (L & 7u) == 0u; }
-__host__ __device__ inline PieceShape piece_shape(uint32_t L, uint32_t W, bool packed = false) {
+__host__ __device__ inline PieceShape piece_shape(uint32_t L, uint32_t W, uint32_t k, bool packed) {
     PieceShape s;
     s.parts = 1u;
+    const uint32_t run_samples = pc_run_samples(k), seg_samples = pc_seg_samples(k), max_len = pc_max_len(k);
     if (packed) {
-        // as many waveforms as fill ~7000 samples AND leave the 2048-word buffer room at 9 bits per sample + a header each
-        const uint32_t by_samples = kPcRunSamples / L, by_words = 2000u / (1u + (9u * L + 31u) / 32u);
+        // as many waveforms as fill ~7000 samples AND leave the 2048-word buffer room at 9 (k + 6) bits per sample + a header each
+        const uint32_t bits = k <= 3u ? 9u : k + 6u;
+        uint32_t by_samples = run_samples / L, by_words = 2000u / (1u + (bits * L + 31u) / 32u);
+        by_samples = by_samples ? by_samples : 1u;
+        by_words = by_words ? by_words : 1u;
         s.run = by_samples < by_words ? by_samples : by_words;
         s.segs = 1u;
         s.seg_len = L;
         s.pieces = (W + s.run - 1u) / s.run;
         s.wgs = (s.pieces + kPcWaves - 1u) / kPcWaves;
-    } else if (L <= kPcRunSamples / 2u) {
-        s.run = kPcRunSamples / L < kPcMaxRun ? kPcRunSamples / L : kPcMaxRun;
+    } else if (L <= run_samples / 2u) {
+        s.run = run_samples / L < kPcMaxRun ? run_samples / L : kPcMaxRun;
         s.segs = 1u;
         s.seg_len = L;
         s.pieces = (W + s.run - 1u) / s.run;
         s.wgs = (s.pieces + kPcWaves - 1u) / kPcWaves;
-    } else if (L <= kPcMaxLen) {
-        const uint32_t need = L <= kPcWholeLen ? 1u : (L + kPcSegSamples - 1u) / kPcSegSamples;
+    } else if (L <= max_len) {
+        const uint32_t need = L <= pc_whole_len(k) ? 1u : (L + seg_samples - 1u) / seg_samples;
         s.run = 1u;
         s.segs = 1u;
         while (s.segs < need) s.segs <<= 1;
@@ -200,7 +219,7 @@ __host__ __device__ inline PieceShape piece_shape(uint32_t L, uint32_t W, bool p
         // segments with a short last part instead were measured slower: nEDM 0.90 against 0.77 ms)
         s.run = 1u;
         s.segs = kPcWaves;
-        s.parts = (uint32_t)(((uint64_t)L + kPcMaxLen - 1u) / kPcMaxLen);
+        s.parts = (uint32_t)(((uint64_t)L + max_len - 1u) / max_len);
         const uint32_t per_part = (uint32_t)(((uint64_t)L + s.parts - 1u) / s.parts);
         s.seg_len = (((per_part + kPcWaves - 1u) / kPcWaves) + 511u) & ~511u;
         s.pieces = 0u;  // (not used: every workgroup of the chunk is full)

@@ -57,7 +57,7 @@ __device__ __forceinline__ uint64_t rfl64(uint64_t v) { return ((uint64_t)rfl((u
 __device__ __forceinline__ PcChunk pc_locate(const Geom &G, uint32_t T, bool packed) {
     PcChunk q;
     if (G.uniform) {
-        const uint32_t wgs = piece_shape(G.u_wave_len, G.u_n_waves, packed).wgs;
+        const uint32_t wgs = piece_shape(G.u_wave_len, G.u_n_waves, G.k, packed).wgs;
         q.c = T / wgs;
         q.j = T - (uint32_t)q.c * wgs;
         q.sample_off = q.c * (uint64_t)G.u_n_samples;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
     PcChunk q = pc_locate(G, T, PACKED);
     q.n_samples = rfl(q.n_samples); q.L = rfl(q.L); q.W = rfl(q.W); q.j = rfl(q.j);
     q.sample_off = rfl64(q.sample_off); q.wave_base = rfl64(q.wave_base); q.c = rfl64(q.c);
-    const PieceShape sh = piece_shape(q.L, q.W, PACKED);
+    const PieceShape sh = piece_shape(q.L, q.W, G.k, PACKED);
     const uint32_t p = rfl(q.j * kPcWaves + wv);  // piece of the chunk
     const bool live = SUPER || p < sh.pieces;
     const bool runs = !SUPER && (PACKED || sh.run > 1u);
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
 // debug_flags: 4096 never this encoder, 8192 always the segment encoder, 32768 this encoder also where WaveformLength is in
 // k_encode_fused's own range (one waveform per wavefront; the tests compare the two that way).
 static bool pieces_packed(const Geom &G) { return G.uniform ? piece_packable(G.u_wave_len) : G.pc_packed != 0; }
-static bool pieces_super(const Geom &G) { return G.uniform ? G.u_wave_len > kPcMaxLen : G.pc_super != 0; }
+static bool pieces_super(const Geom &G) { return G.uniform ? G.u_wave_len > pc_max_len(G.k) : G.pc_super != 0; }
 
 bool pieces_batch(const Geom &G) {
     if ((G.n_taps && !G.enc_fast) || (G.dbg & (8192u | 4096u))) return false;  // delta, or a forward filter of up to four taps
@@ -676,7 +676,7 @@ bool pieces_batch(const Geom &G) {
         const bool packed = piece_packable(L);
         if (L < kPcMinLen && !packed) return false;
         if ((uint64_t)G.n_chunks * G.u_n_samples < (uint64_t)kTile) return false;
-        const PieceShape sh = piece_shape(L, G.u_n_waves, packed);
+        const PieceShape sh = piece_shape(L, G.u_n_waves, G.k, packed);
         if ((uint64_t)G.u_n_waves * sh.parts > 0x7fffffffull || (uint64_t)sh.wgs * G.n_chunks > 0x7fffffffull) return false;
         return force || packed || sh.run > 1u || sh.segs > 1u;
     }
@@ -685,9 +685,9 @@ bool pieces_batch(const Geom &G) {
 
 uint64_t pieces_workgroups(const Geom &G, const ChunkDesc *host_chunks) {
     const bool packed = pieces_packed(G);
-    if (G.uniform) return (uint64_t)piece_shape(G.u_wave_len, G.u_n_waves, packed).wgs * G.n_chunks;
+    if (G.uniform) return (uint64_t)piece_shape(G.u_wave_len, G.u_n_waves, G.k, packed).wgs * G.n_chunks;
     uint64_t t = 0;
-    for (uint64_t c = 0; c < G.n_chunks; ++c) t += piece_shape(host_chunks[c].wave_len, host_chunks[c].n_waves, packed).wgs;
+    for (uint64_t c = 0; c < G.n_chunks; ++c) t += piece_shape(host_chunks[c].wave_len, host_chunks[c].n_waves, G.k, packed).wgs;
     return t;
 }
 

@@ -11,6 +11,7 @@
   nedm_fir4      the nEDM shape with that filter
   raglong    a ragged batch of few long waveforms: 48 chunks, WaveformLength in {81 920, 500 000, 250 000, whole chunk}
   raglong_fir4   the same with taps [1,-1,1,-1]
+  nab100     100 chunks of 2000 x 7000 (a fifth of the headline batch; with --sigma / --m: noisier data)
   nab1       ONE chunk of 2000 x 7000 (what one H5Z call sees, docs/Performance.md:16)
   small20    ONE chunk of 20 x 7000  (README.md:75-82, BASELINE config #1's chunk)
   small100   ONE chunk of 100 x 7000
@@ -59,6 +60,8 @@ def geometry(name):
         return [32 * 81920] * 256, [81920] * 256
     if name == "noptrex":
         return [32 * 500000] * 64, [500000] * 64
+    if name == "nab100":
+        return [2000 * 7000] * 100, [7000] * 100
     if name == "nab1":
         return [2000 * 7000], [7000]
     if name == "small20":
@@ -73,6 +76,7 @@ def main():
     ap.add_argument("name")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--m", type=int, default=8)
+    ap.add_argument("--sigma", type=float, default=10.0, help="standard deviation of the Gaussian samples")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--debug-flags", type=int, default=0)
     ap.add_argument("--sideband", action="store_true", help="decode with the encoder's n_i table as a side-band (drx_decode_with_wave_words)")
@@ -89,7 +93,7 @@ def main():
     slab = 1 << 28
     for s0 in range(0, total, slab):
         n = min(slab, total - s0)
-        x[s0:s0 + n] = (torch.randn(n, device=ctx.device, generator=g) * 10).to(torch.int16)
+        x[s0:s0 + n] = (torch.randn(n, device=ctx.device, generator=g) * a.sigma).to(torch.int16)
     uniform = len(set(Ns)) == 1 and len(set(Ls)) == 1
     taps = FIR4 if a.name.endswith("_fir4") else None
     if uniform:
@@ -138,7 +142,7 @@ def main():
     ratio = nwords * 4 / raw
     algo = raw * (1 + ratio)
     print(json.dumps({
-        "workload": a.name, "chunks": len(Ns), "samples": total, "m": a.m, "ratio": ratio, "decode_path": plan.last_decode_path(),
+        "workload": a.name, "sigma": a.sigma, "chunks": len(Ns), "samples": total, "m": a.m, "ratio": ratio, "decode_path": plan.last_decode_path(),
         "encode_ms": {"prepare": float(te[0]), "scan": float(te[1]), "pack": float(te[2]), "total": float(te[3])},
         "decode_ms": {"walk": float(td[0]), "decode": float(td[1]), "total": float(td[3])},
         "encode_GBps_int16": raw / te[3] / 1e6, "decode_GBps_int16": raw / td[3] / 1e6,

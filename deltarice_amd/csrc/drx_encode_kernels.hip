@@ -318,13 +318,20 @@ constexpr int kLbWin = DRX_ENC_LB_WIN;  // look-back window of k_encode_fused in
 #ifndef DRX_ENC_WAVES_PER_EU
 #define DRX_ENC_WAVES_PER_EU 1
 #endif
-template <bool GEN>
-__global__ __launch_bounds__(64 * kEncWaves, DRX_ENC_WAVES_PER_EU) void k_encode_fused(Geom G, const int16_t *__restrict__ in,
+// WV x CAPW: waveforms per workgroup x LDS words per waveform.  8 x 2048 (9.3 bits per sample at WaveformLength 7000) is the
+// measured geometry of the headline workload; noisier data with the RiceParameter that suits it needs k + 3.5 bits per
+// sample, and a waveform whose code outgrows its buffer is coded twice -- 8 x 2496 (two workgroups per CU), 4 x 3072 (three)
+// and 4 x 4096 words (two) keep the single pass for it (fused_wide(), drx_internal.h).  Six waveforms per workgroup were
+// measured a third slower whatever the buffer (three of them on two SIMDs, one each on the others).
+template <bool GEN, int WV = DRX_ENC_WAVES, uint32_t CAPW = kEncCapWords>
+__global__ __launch_bounds__(64 * WV, DRX_ENC_WAVES_PER_EU) void k_encode_fused(Geom G, const int16_t *__restrict__ in,
                                                       uint32_t *__restrict__ out, uint64_t out_cap,
                                                       uint64_t *__restrict__ chunk_word_off,
                                                       uint32_t *__restrict__ wave_words,
                                                       uint64_t *__restrict__ scan_state,
                                                       uint32_t *__restrict__ ticket, DevStatus *st) {
+    constexpr int kEncWaves = WV;             // (shadow the namespace-scope defaults)
+    constexpr uint32_t kEncCapWords = CAPW;
     // per waveform: 4 pad words (emit_tile_concat ORs zeros below a lane's first word), the code, 4 slack words
     __shared__ __attribute__((aligned(16))) uint32_t buf_all[kEncWaves][kEncCapWords + 8];
     __shared__ uint32_t s_ticket;
@@ -830,12 +837,23 @@ hipError_t launch_encode_fused(const Geom &G, const int16_t *d_in, uint32_t *d_o
     mark(ev, 1, s);
     mark(ev, 2, s);
     uint32_t *ticket = reinterpret_cast<uint32_t *>(d_scan + G.total_waves);
-    if (G.n_taps)
-        k_encode_fused<true><<<blocks_for(G.total_waves, kEncWaves), 64 * kEncWaves, 0, s>>>(G, d_in, d_out, out_cap, d_chunk_word_off,
-                                                                                      d_wave_words, d_scan, ticket, d_status);
-    else
-        k_encode_fused<false><<<blocks_for(G.total_waves, kEncWaves), 64 * kEncWaves, 0, s>>>(G, d_in, d_out, out_cap, d_chunk_word_off,
-                                                                                       d_wave_words, d_scan, ticket, d_status);
+    auto go = [&](auto gen_tag, auto wv_tag, auto cap_tag) {
+        constexpr bool GEN = decltype(gen_tag)::value;
+        constexpr int WV = decltype(wv_tag)::value;
+        constexpr uint32_t CAPW = decltype(cap_tag)::value;
+        k_encode_fused<GEN, WV, CAPW><<<blocks_for(G.total_waves, WV), 64 * WV, 0, s>>>(G, d_in, d_out, out_cap, d_chunk_word_off, d_wave_words,
+                                                                                    d_scan, ticket, d_status);
+    };
+    using std::integral_constant;
+    const std::true_type T;
+    const std::false_type F;
+    auto pick = [&](auto wv_tag, auto cap_tag) { if (G.n_taps) go(T, wv_tag, cap_tag); else go(F, wv_tag, cap_tag); };
+    switch (fused_wide(G)) {
+        case 1: pick(integral_constant<int, 8>{}, integral_constant<uint32_t, kEncWide1Words>{}); break;
+        case 2: pick(integral_constant<int, 4>{}, integral_constant<uint32_t, kEncWide2Words>{}); break;
+        case 3: pick(integral_constant<int, 4>{}, integral_constant<uint32_t, kEncWide3Words>{}); break;
+        default: pick(integral_constant<int, kEncWaves>{}, integral_constant<uint32_t, kEncCapWords>{}); break;
+    }
     mark(ev, 3, s);
     return hipGetLastError();
 }

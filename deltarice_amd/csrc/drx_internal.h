@@ -227,6 +227,19 @@ __host__ __device__ inline PieceShape piece_shape(uint32_t L, uint32_t W, uint32
     }
     return s;
 }
+// k_encode_fused's own range of WaveformLengths (uniform batches), a RiceParameter beyond the measured geometry, and a waveform
+// that would not stay whole in the standard 2048-word buffer: larger buffers, fewer waveforms per workgroup --
+// 1 = 8 waveforms x 2496 words, 2 = 4 x 3072, 3 = 4 x 4096 -- where the waveform fits at k + 4.4 bits per sample; 0 = the
+// standard geometry (or, beyond all of them, the pieces encoder's segments).  100 chunks of 2000 x 7000, sigma = 80, m = 64
+// (9.5 bits per sample): coded twice 2.17 ms, two segments 1.87, 4 x 3072 1.56, 8 x 3072 (one workgroup per CU) 1.64, 6 x 3072 2.08.
+constexpr uint32_t kEncWide1Words = 2496, kEncWide2Words = 3072, kEncWide3Words = 4096;
+inline int fused_wide(const Geom &G) {
+    if (!G.uniform || G.k <= 3u || (G.dbg & 65536u)) return 0;
+    const uint32_t L = G.u_wave_len;
+    if (L <= kPcRunSamples / 2u || L > kPcWholeLen || L <= pc_whole_len(G.k)) return 0;
+    const uint64_t bits10 = (uint64_t)L * (10u * G.k + 44u);
+    return bits10 <= 320ull * kEncWide1Words ? 1 : (bits10 <= 320ull * kEncWide2Words ? 2 : (bits10 <= 320ull * kEncWide3Words ? 3 : 0));
+}
 bool pieces_batch(const Geom &G);       // the batch takes this encoder
 uint64_t pieces_workgroups(const Geom &G, const ChunkDesc *host_chunks);
 uint64_t pieces_scan_words(const Geom &G, uint64_t total_wgs);  // uint64 words of its look-back state

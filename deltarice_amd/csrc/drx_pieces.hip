@@ -678,6 +678,7 @@ bool pieces_batch(const Geom &G) {
         if ((uint64_t)G.n_chunks * G.u_n_samples < (uint64_t)kTile) return false;
         const PieceShape sh = piece_shape(L, G.u_n_waves, G.k, packed);
         if ((uint64_t)G.u_n_waves * sh.parts > 0x7fffffffull || (uint64_t)sh.wgs * G.n_chunks > 0x7fffffffull) return false;
+        if (!force && fused_wide(G)) return false;  // k_encode_fused with a larger buffer per waveform
         return force || packed || sh.run > 1u || sh.segs > 1u;
     }
     return G.pc_wg_base != nullptr;  // decided when the plan was made

@@ -173,7 +173,7 @@ drx_status drx_plan_last_timings(drx_plan *plan, float ms[4]);
  *   "debug_flags"  dispatch overrides that force an alternative (still bit-exact) path, for tests and A/B timing:
  *        256 never the long-waveform paths, 512 long waveforms one workgroup each, 2048 never the parallel header walks,
  *        4096 never the pieces encoder, 8192 always the segment encoder, 32768 the pieces encoder also where one wavefront per
- *        waveform is the default.  (Ablation switches inside the kernels exist only in -DDRX_ABLATION builds.) */
+ *        waveform is the default, 65536 never the single-pass encoder's larger-buffer geometries (RiceParameter above 8).  (Ablation switches inside the kernels exist only in -DDRX_ABLATION builds.) */
 drx_status drx_ctx_set_option(drx_ctx *ctx, const char *key, int64_t value);
 
 #ifdef __cplusplus

@@ -101,8 +101,8 @@ def main():
                 plan = ctx.plan_uniform(n_chunks, Ns[0], opts)
             xd = dev(ctx, x)
             # (256: no long-waveform paths; 4096: no pieces encoder; 8192: the segment encoder; 32768: the pieces encoder
-            # wherever its geometry allows)
-            for flags in (0, 256, 4096, 8192, 32768):
+            # wherever its geometry allows; 65536: the single-pass encoder's standard geometry only)
+            for flags in (0, 256, 4096, 8192, 32768, 65536):
                 ctx.set_option("debug_flags", flags)
                 for eimpl in ((1, 0) if flags in (0, 256) else (1,)):
                     ctx.set_option("encode_impl", eimpl)

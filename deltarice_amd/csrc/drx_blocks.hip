@@ -44,9 +44,15 @@
 
 namespace drx {
 
-constexpr int kBlkSegW = 11;             // words per lane (odd): 54 samples at 6.5 bits per sample
-constexpr uint32_t kBlkLaneCap = 76;     // samples a lane can leave in its share of the staging buffer (+ 4.8 sigma)
-constexpr uint32_t kBlkLaneStride = kBlkLaneCap / 2u + 1u;  // dwords per lane: 38 of samples + a dump slot (odd: no bank conflicts)
+// Words per lane (odd: the lanes' windows fall on different banks) and the samples a lane can leave in its share of the
+// staging buffer, by RiceParameter.  A block is a fixed number of BITS and costs about the same whatever it holds, so with
+// 352 bits per lane the decoder slowed down as the samples grew (12.75 bits per sample: 27 samples per lane; NOPTREX 0.25 ->
+// 0.18 of the roofline, 25 x 14 M samples 0.19 -> 0.10): noisier data gets longer segments and a smaller share of the
+// staging buffer, ~50 samples per lane and the same 50 dwords of LDS per lane in every class --
+//   k <= 4: 11 words, 76 samples (54 samples at 6.5 bits, the measured geometry)   5 <= k <= 7: 15 words, 68 samples
+//   k >= 8: 19 words, 60 samples.
+__host__ __device__ constexpr int blk_segw(uint32_t k) { return k <= 4u ? 11 : (k <= 7u ? 15 : 19); }
+__host__ __device__ constexpr uint32_t blk_lane_cap(int segw) { return segw == 11 ? 76u : (segw == 15 ? 68u : 60u); }
 constexpr uint32_t kBlkPre = 8;          // words kept in front of a block: lane 0's run-up
 #ifndef DRX_BLK_GUESS_BITS
 #define DRX_BLK_GUESS_BITS 128
@@ -60,16 +66,19 @@ constexpr uint32_t kBlkRounds = DRX_BLK_ROUNDS;  // tickets per resident workgro
 constexpr uint32_t kBlkTail = 4;         // words behind a block: a code that starts inside may end 24 bits behind it,
                                          // and a window reads three words
 
-template <int NT>
+template <int NT, int SW>
 struct BlkGeom {
-    static constexpr uint32_t kWords = NT * kBlkSegW;                       // payload words per block
+    static constexpr int kSegW = SW;
+    static constexpr uint32_t kLaneCap = blk_lane_cap(SW);                  // samples a lane can stage
+    static constexpr uint32_t kLaneStride = kLaneCap / 2u + 1u;             // dwords per lane: the samples + a dump slot (odd: no bank conflicts)
+    static constexpr uint32_t kWords = NT * SW;                             // payload words per block
     static constexpr uint32_t kLdsWords = kBlkPre + kWords + kBlkTail + 4;  // + up to 3 words of 16-byte alignment
-    static constexpr uint32_t kOutCap = NT * kBlkLaneCap;                   // samples staged per copy-out
-    static constexpr uint32_t kStageWords = NT * kBlkLaneStride;            // the staging buffer, lane-major or output order
+    static constexpr uint32_t kOutCap = NT * kLaneCap;                      // samples staged per copy-out
+    static constexpr uint32_t kStageWords = NT * kLaneStride;               // the staging buffer, lane-major or output order
     static_assert(kLdsWords % 4 == 0, "the image is filled by 16-byte pieces");
 };
 
-__host__ __device__ inline uint32_t blk_words(uint32_t nt) { return nt * kBlkSegW; }
+__host__ __device__ inline uint32_t blk_words(uint32_t nt, uint32_t k) { return nt * (uint32_t)blk_segw(k); }
 
 // Most blocks any waveform of the batch has: info[0]; tickets of the decode launch: info[1] = info[0] x waveforms.
 // One workgroup.
@@ -176,12 +185,12 @@ __device__ __forceinline__ uint32_t unzigzag(uint32_t z) { return (z >> 1) ^ (0u
 template <int MODE, bool RESID = false, bool PAD = true>
 __device__ __forceinline__ void blk_parse(const uint32_t *W, uint32_t k, bool enable, uint32_t &Qp, uint32_t qlim,
                                           uint32_t &c, uint32_t &sum, uint32_t cmax, uint16_t *outp, uint32_t *stage = nullptr,
-                                          uint32_t qpad = 0u) {
+                                          uint32_t qpad = 0u, uint32_t cap2 = 0u) {  // cap2: the dump slot = half the lane's share
     auto more = [&](uint32_t q, uint32_t cc) __attribute__((always_inline)) {
         return enable && (MODE == kBlkValue ? cc < cmax : (int32_t)(q - qlim) > 0);
     };
     // staging slot of the next pair (kBlkCount; c is even whenever a pair is staged): a dword index that saturates at the dump slot
-    uint32_t slot = (c >> 1) < kBlkLaneCap / 2u ? (c >> 1) : kBlkLaneCap / 2u;
+    uint32_t slot = (c >> 1) < cap2 ? (c >> 1) : cap2;
     while (__builtin_amdgcn_ballot_w64(more(Qp, c)) != 0ull) {  // (__any() costs a v_cndmask and a v_cmp more)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {  // one vote per four codes
@@ -202,7 +211,7 @@ __device__ __forceinline__ void blk_parse(const uint32_t *W, uint32_t k, bool en
                 }
                 if (MODE == kBlkCount) {  // c is even here: only a lane's last pair can end after its first code
                     if (act1) stage[slot] = __builtin_amdgcn_perm(s2, s1, 0x05040100u);
-                    slot = slot + 1u < kBlkLaneCap / 2u ? slot + 1u : kBlkLaneCap / 2u;
+                    slot = slot + 1u < cap2 ? slot + 1u : cap2;
                 }
                 sum = act2 ? s2 : (act1 ? s1 : sum);
             }
@@ -219,7 +228,7 @@ __device__ __forceinline__ void blk_parse(const uint32_t *W, uint32_t k, bool en
 // limit test is an unsigned compare.
 template <bool RESID>
 __device__ __forceinline__ void blk_count_pairs(const uint32_t *W, uint32_t k, bool enable, uint32_t &Qp, uint32_t qlim,
-                                                uint32_t &c, uint32_t &sum, uint32_t *stage) {
+                                                uint32_t &c, uint32_t &sum, uint32_t *stage, uint32_t cap2) {
     uint32_t slot = 0, Qa_l = Qp, s1_l = sum;  // (c = 0 on entry)
     bool act = enable && Qp > qlim;
     while (__builtin_amdgcn_ballot_w64(act) != 0ull) {
@@ -236,7 +245,7 @@ __device__ __forceinline__ void blk_count_pairs(const uint32_t *W, uint32_t k, b
                 c += 2u;
                 Qp = Qa_l + p.nu2;
             }
-            slot = slot + 1u < kBlkLaneCap / 2u ? slot + 1u : kBlkLaneCap / 2u;
+            slot = slot + 1u < cap2 ? slot + 1u : cap2;
             act = act && Qp > qlim;
         }
     }
@@ -261,7 +270,7 @@ __device__ __forceinline__ void blk_skip_pairs(const uint32_t *W, uint32_t k, bo
     if (enable && !(Qa_l > qlim)) Qp = Qa_l;  // (no pair taken: Qa_l is Qp)
 }
 
-template <int NT, bool RESID = false>
+template <int NT, bool RESID, int SW>
 __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
                                                       const uint64_t *__restrict__ wave_off,
                                                       const uint32_t *__restrict__ wave_words,
@@ -271,7 +280,9 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
                                                       uint32_t *__restrict__ fail, uint32_t *__restrict__ suspect,
                                                       DevStatus *st, int16_t *__restrict__ out, unsigned long long *prof,
                                                       const uint32_t *__restrict__ wave_list, uint32_t n_list) {
-    using BG = BlkGeom<NT>;
+    using BG = BlkGeom<NT, SW>;
+    constexpr int kBlkSegW = SW;
+    constexpr uint32_t kBlkLaneCap = BG::kLaneCap, kBlkLaneStride = BG::kLaneStride, kCap2 = BG::kLaneCap / 2u;
     constexpr uint32_t K = BG::kLdsWords + 2u;  // word w of the image sits at W[K + 1 - w]; K = 2 (mod 4): 16-byte quads
     constexpr uint32_t C = 32u * K;
     constexpr int NW = NT / 64;
@@ -447,8 +458,8 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
             uint32_t *const my_stage = stage + tid * kBlkLaneStride;
             // where the waveform's zero padding can be: its last payload word, if this block holds it
             const uint32_t qpad = (n - 1u >= w0 && n - 1u < w0 + BG::kWords) ? C - (B0 + 32u * (n - 1u - w0)) : 0u;
-            if (qpad) blk_parse<kBlkCount, RESID, true>(W, k, active, Qp, C - lim, cnt, sum, 0u, nullptr, my_stage, qpad);
-            else blk_count_pairs<RESID>(W, k, active, Qp, C - lim, cnt, sum, my_stage);
+            if (qpad) blk_parse<kBlkCount, RESID, true>(W, k, active, Qp, C - lim, cnt, sum, 0u, nullptr, my_stage, qpad, kCap2);
+            else blk_count_pairs<RESID>(W, k, active, Qp, C - lim, cnt, sum, my_stage, kCap2);
             if (!active) { cnt = 0; sum = 0; }
             uint32_t e = C - Qp;  // first code that starts behind it (or where the padding starts)
             BLK_STAMP(2);  // run-up + count (thread 0's wave)
@@ -462,7 +473,7 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
                     const bool changed = active && want != f;
                     if (!wg_any(changed)) break;  // (also: every read of s_e is done before the next write)
                     if (changed) { f = want; Qp = C - f; cnt = 0; sum = 0; }
-                    blk_parse<kBlkCount, RESID>(W, k, changed, Qp, C - lim, cnt, sum, 0u, nullptr, my_stage, qpad);
+                    blk_parse<kBlkCount, RESID>(W, k, changed, Qp, C - lim, cnt, sum, 0u, nullptr, my_stage, qpad, kCap2);
                     if (changed) e = C - Qp;
                 }
             };
@@ -490,7 +501,7 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
                 const bool fix0 = tid == 0 && true_f0 != f;
                 if (wg_any(fix0)) {
                     if (fix0) { f = true_f0; Qp = C - f; cnt = 0; sum = 0; }
-                    blk_parse<kBlkCount, RESID>(W, k, fix0, Qp, C - lim, cnt, sum, 0u, nullptr, my_stage, qpad);
+                    blk_parse<kBlkCount, RESID>(W, k, fix0, Qp, C - lim, cnt, sum, 0u, nullptr, my_stage, qpad, kCap2);
                     if (fix0) e = C - Qp;
                     settle();
                     // a one-block run has published its end already, and its successor has started from it: if that end
@@ -688,7 +699,7 @@ static int nt_for_len(uint32_t wave_len, uint32_t k) {
     return DRX_BLK_FORCE_NT;
 #endif
     const uint64_t typ_words = ((uint64_t)wave_len * (2u * k + 7u)) >> 6;
-    return typ_words <= blk_words(64) ? 64 : (typ_words <= blk_words(128) ? 128 : 256);
+    return typ_words <= blk_words(64, k) ? 64 : (typ_words <= blk_words(128, k) ? 128 : 256);
 }
 static int blocks_nt(const Geom &G) { return G.uniform ? nt_for_len(G.u_wave_len, G.k) : (int)G.rag_blk_nt; }
 
@@ -697,12 +708,13 @@ static int blocks_nt(const Geom &G) { return G.uniform ? nt_for_len(G.u_wave_len
 // chunks of 1166 x 12 000 and of 854 x 16 384)
 static double blocks_weighted(uint64_t waves, uint32_t wave_len, uint32_t k, int nt) {
     const uint64_t typ_words = ((uint64_t)wave_len * (2u * k + 7u)) >> 6;
-    const uint64_t bpw = (typ_words + blk_words((uint32_t)nt) - 1u) / blk_words((uint32_t)nt);
+    const uint64_t bpw = (typ_words + blk_words((uint32_t)nt, k) - 1u) / blk_words((uint32_t)nt, k);
     return (double)(waves * bpw) * (bpw <= 2u ? 1.7 : 1.0);
 }
-static double blocks_us_of(double weighted_blocks, int nt) {
+static double blocks_us_of(double weighted_blocks, int nt, uint32_t k) {
     const double resident = nt == 256 ? 768.0 : (nt == 128 ? 1536.0 : 3072.0);
-    const double t_blk = nt == 256 ? 21.0 : (nt == 128 ? 28.0 : 41.0);
+    // (measured with 11 words per lane; a block's time goes with its bits)
+    const double t_blk = (nt == 256 ? 21.0 : (nt == 128 ? 28.0 : 41.0)) * (double)blk_segw(k) / 11.0;
     return (double)(uint64_t)((weighted_blocks + resident - 1.0) / resident) * t_blk;  // whole rounds of the resident grid
 }
 
@@ -719,8 +731,8 @@ bool blocks_batch(const Geom &G) {
     if (!(G.total_waves <= 98304u && G.u_wave_len >= 2048u)) return false;
     const int nt = blocks_nt(G);
     const uint64_t typ_words = ((uint64_t)G.u_wave_len * (2u * G.k + 7u)) >> 6;
-    const uint64_t bpw = (typ_words + blk_words((uint32_t)nt) - 1u) / blk_words((uint32_t)nt);
-    const double blocks_us = blocks_us_of((double)(G.total_waves * bpw), nt) * (bpw <= 2u ? 1.7 : 1.0);
+    const uint64_t bpw = (typ_words + blk_words((uint32_t)nt, G.k) - 1u) / blk_words((uint32_t)nt, G.k);
+    const double blocks_us = blocks_us_of((double)(G.total_waves * bpw), nt, G.k) * (bpw <= 2u ? 1.7 : 1.0);
     const double lanes_us = 0.06 * (double)G.u_wave_len * (double)((G.total_waves + 98303u) / 98304u);
     return blocks_us < lanes_us;
 }
@@ -739,9 +751,9 @@ void blocks_plan_ragged(Geom &G, const ChunkDesc *d, uint32_t *list_out) {
     for (uint64_t c = 0; c < G.n_chunks; ++c) wb += blocks_weighted(d[c].n_waves, d[c].wave_len, G.k, nt);
     // a lane takes 60 ns per sample: a lane-per-waveform launch lasts as long as its longest waveform, per 98 304 of them
     const double lanes_us = 0.06 * (double)max_len * (double)((G.total_waves + 98303u) / 98304u);
-    if (!(blocks_us_of(wb, nt) < lanes_us)) return;
+    if (!(blocks_us_of(wb, nt, G.k) < lanes_us)) return;
     // look-back slots per waveform: enough for the longest one at 25 bits per sample, in blocks of the SMALLEST class's size
-    const uint64_t per = (max_payload_words(max_len) + blk_words(64u) - 1u) / blk_words(64u);
+    const uint64_t per = (max_payload_words(max_len) + blk_words(64u, G.k) - 1u) / blk_words(64u, G.k);
     if (G.total_waves * per * 12u > (1ull << 30)) return;  // (one very long waveform among very many: the table would not pay)
     G.rag_blocks = 1u;
     G.rag_blk_nt = (uint32_t)nt;
@@ -767,7 +779,7 @@ void blocks_plan_ragged(Geom &G, const ChunkDesc *d, uint32_t *list_out) {
 
 static uint32_t blocks_slots_per_wave(const Geom &G) {  // blocks of a waveform at 25 bits per sample
     if (!G.uniform) return G.rag_blk_slots;
-    const uint64_t per = (max_payload_words(G.u_wave_len) + blk_words(blocks_nt(G)) - 1u) / blk_words(blocks_nt(G));
+    const uint64_t per = (max_payload_words(G.u_wave_len) + blk_words(blocks_nt(G), G.k) - 1u) / blk_words(blocks_nt(G), G.k);
     return (uint32_t)(per ? per : 1u);
 }
 
@@ -809,7 +821,7 @@ hipError_t launch_decode_blocks(const Geom &G, const uint32_t *d_in, uint64_t in
     const uint32_t spw = blocks_slots_per_wave(G);
     auto launch_class = [&](uint32_t cls, const uint32_t *list, uint32_t n_waves, int nt, uint32_t wave_len) {
         uint32_t *info = L.info + 4u * cls;
-        k_blk_max<<<1, 1024, 0, s>>>(n_waves, d_wave_words, blk_words((uint32_t)nt), info, list);
+        k_blk_max<<<1, 1024, 0, s>>>(n_waves, d_wave_words, blk_words((uint32_t)nt, G.k), info, list);
         const uint64_t units = (uint64_t)n_waves * spw;
         // Runs of several blocks only when two runs of one waveform are never in flight together (see the kernel): at least
         // as many waveforms as resident workgroups.  Then as long as the launch keeps kBlkRounds tickets per workgroup (the
@@ -817,20 +829,31 @@ hipError_t launch_decode_blocks(const Geom &G, const uint32_t *d_in, uint64_t in
         // blocks per waveform: one run; NOPTREX, 36: three runs of 12: 1.40 / 0.98 ms against 1.43 / 1.00 with round 2's fixed 4).
         const uint32_t resident = 256u * (nt == 64 ? 12u : (nt == 128 ? 6u : 3u));
         const uint64_t typ_words = ((uint64_t)wave_len * (2u * G.k + 7u)) >> 6;
-        const uint64_t bpw = (typ_words + blk_words((uint32_t)nt) - 1u) / blk_words((uint32_t)nt);
+        const uint64_t bpw = (typ_words + blk_words((uint32_t)nt, G.k) - 1u) / blk_words((uint32_t)nt, G.k);
         uint64_t rl = ((uint64_t)n_waves * bpw) / ((uint64_t)kBlkRounds * resident);
         rl = rl > bpw ? bpw : rl;
         const uint32_t run_len = n_waves >= resident ? (uint32_t)(rl < 1u ? 1u : rl) : 1u;
-        auto go = [&](auto nt_tag, auto resid_tag, unsigned per_cu) {
-            constexpr int NT = decltype(nt_tag)::value;
+        auto go = [&](auto nt_tag, auto resid_tag, auto sw_tag, unsigned per_cu) {
+            constexpr int NT = decltype(nt_tag)::value, SW = decltype(sw_tag)::value;
             constexpr bool RESID = decltype(resid_tag)::value;
             const unsigned grid = (unsigned)(units < 256u * per_cu ? units : 256u * per_cu);
-            k_decode_blocks<NT, RESID><<<grid, NT, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, info, spw, run_len, L.state, L.ends,
-                                                           info + 2, L.fail, L.suspect, d_status, d_out, L.prof, list, n_waves);
+            k_decode_blocks<NT, RESID, SW><<<grid, NT, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, info, spw, run_len, L.state, L.ends,
+                                                               info + 2, L.fail, L.suspect, d_status, d_out, L.prof, list, n_waves);
         };
-        if (nt == 64) { if (resid) go(std::integral_constant<int, 64>{}, std::true_type{}, 12u); else go(std::integral_constant<int, 64>{}, std::false_type{}, 12u); }
-        else if (nt == 128) { if (resid) go(std::integral_constant<int, 128>{}, std::true_type{}, 6u); else go(std::integral_constant<int, 128>{}, std::false_type{}, 6u); }
-        else { if (resid) go(std::integral_constant<int, 256>{}, std::true_type{}, 3u); else go(std::integral_constant<int, 256>{}, std::false_type{}, 3u); }
+        auto by_sw = [&](auto nt_tag, auto resid_tag, unsigned per_cu) {
+            switch (blk_segw(G.k)) {
+                case 11: go(nt_tag, resid_tag, std::integral_constant<int, 11>{}, per_cu); break;
+                case 15: go(nt_tag, resid_tag, std::integral_constant<int, 15>{}, per_cu); break;
+                default: go(nt_tag, resid_tag, std::integral_constant<int, 19>{}, per_cu); break;
+            }
+        };
+        auto by_resid = [&](auto nt_tag, unsigned per_cu) {
+            if (resid) by_sw(nt_tag, std::true_type{}, per_cu); else by_sw(nt_tag, std::false_type{}, per_cu);
+        };
+        // resident workgroups per CU by LDS: 50 dwords per lane in every class
+        if (nt == 64) by_resid(std::integral_constant<int, 64>{}, 12u);
+        else if (nt == 128) by_resid(std::integral_constant<int, 128>{}, 6u);
+        else by_resid(std::integral_constant<int, 256>{}, 3u);
     };
     if (G.uniform) {
         launch_class(0u, nullptr, (uint32_t)G.total_waves, blocks_nt(G), G.u_wave_len);

@@ -362,6 +362,7 @@ drx_status drx_plan_create(drx_ctx *ctx, uint64_t n_chunks, const uint32_t *chun
     p->G.u_wave_len = desc[0].wave_len;
     p->G.u_n_waves = desc[0].n_waves;
     p->G.k = rice_k;
+    p->G.total_samples = soff;
     drx_status st = plan_alloc(ctx, p);
     if (st == DRX_OK && !uniform) {
         hipError_t e = hipMalloc((void **)&p->d_chunks, n_chunks * sizeof(ChunkDesc));
@@ -513,6 +514,7 @@ drx_status drx_plan_create_uniform(drx_ctx *ctx, uint64_t n_chunks, uint32_t chu
     p->G.u_wave_len = L;
     p->G.u_n_waves = W;
     p->G.k = rice_k;
+    p->G.total_samples = p->total_samples;
     drx_status st = plan_alloc(ctx, p);
     if (st == DRX_OK) st = plan_alloc_scratch(ctx, p);
     if (st != DRX_OK) { plan_free(p); return st; }

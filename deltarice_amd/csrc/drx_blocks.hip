@@ -45,14 +45,22 @@
 namespace drx {
 
 // Words per lane (odd: the lanes' windows fall on different banks) and the samples a lane can leave in its share of the
-// staging buffer, by RiceParameter.  A block is a fixed number of BITS and costs about the same whatever it holds, so with
-// 352 bits per lane the decoder slowed down as the samples grew (12.75 bits per sample: 27 samples per lane; NOPTREX 0.25 ->
-// 0.18 of the roofline, 25 x 14 M samples 0.19 -> 0.10): noisier data gets longer segments and a smaller share of the
-// staging buffer, ~50 samples per lane and the same 50 dwords of LDS per lane in every class --
-//   k <= 4: 11 words, 76 samples (54 samples at 6.5 bits, the measured geometry)   5 <= k <= 7: 15 words, 68 samples
-//   k >= 8: 19 words, 60 samples.
-__host__ __device__ constexpr int blk_segw(uint32_t k) { return k <= 4u ? 11 : (k <= 7u ? 15 : 19); }
-__host__ __device__ constexpr uint32_t blk_lane_cap(int segw) { return segw == 11 ? 76u : (segw == 15 ? 68u : 60u); }
+// staging buffer.  A block is a fixed number of BITS and costs about the same whatever it holds, so one geometry for all
+// data loses both ways: with 352 bits per lane noisy data (12.75 bits per sample: 27 samples per lane) decoded at 0.18
+// instead of 0.25 of the roofline, and quiet data under the reference's default RiceParameter (4 bits per sample: 88
+// samples per lane, more than the 76 its share holds, so EVERY block took the second parse) at 0.16.  The class is chosen
+// per decode from what the caller states about the stream -- 32 in_words / total_samples bits per sample, so a
+// RiceParameter that does not suit the data is covered too -- for ~50 samples per lane with 15 % to spare, and every class
+// takes 48-50 dwords of LDS per lane:
+//   words per lane        9      11      15      19
+//   samples staged       76      76      68      60
+//   bits per sample   < 5.4   < 8.2  < 11.7    above
+// Plan-time estimates (which decoder a batch takes, lanes per block) assume the class that suits the RiceParameter;
+// scratch is sized for the smallest blocks.
+constexpr int kBlkSegWMin = 9;
+__host__ __device__ constexpr int blk_segw_plan(uint32_t k) { return k <= 4u ? 11 : (k <= 7u ? 15 : 19); }
+__host__ __device__ constexpr int blk_segw_bits10(uint64_t b10) { return b10 >= 117u ? 19 : (b10 >= 82u ? 15 : (b10 >= 54u ? 11 : 9)); }
+__host__ __device__ constexpr uint32_t blk_lane_cap(int segw) { return segw <= 11 ? 76u : (segw == 15 ? 68u : 60u); }
 constexpr uint32_t kBlkPre = 8;          // words kept in front of a block: lane 0's run-up
 #ifndef DRX_BLK_GUESS_BITS
 #define DRX_BLK_GUESS_BITS 128
@@ -78,7 +86,8 @@ struct BlkGeom {
     static_assert(kLdsWords % 4 == 0, "the image is filled by 16-byte pieces");
 };
 
-__host__ __device__ inline uint32_t blk_words(uint32_t nt, uint32_t k) { return nt * (uint32_t)blk_segw(k); }
+__host__ __device__ inline uint32_t blk_words(uint32_t nt, uint32_t k) { return nt * (uint32_t)blk_segw_plan(k); }  // plan-time estimates
+__host__ __device__ inline uint32_t blk_words_min(uint32_t nt) { return nt * (uint32_t)kBlkSegWMin; }               // scratch sizing
 
 // Most blocks any waveform of the batch has: info[0]; tickets of the decode launch: info[1] = info[0] x waveforms.
 // One workgroup.
@@ -714,7 +723,7 @@ static double blocks_weighted(uint64_t waves, uint32_t wave_len, uint32_t k, int
 static double blocks_us_of(double weighted_blocks, int nt, uint32_t k) {
     const double resident = nt == 256 ? 768.0 : (nt == 128 ? 1536.0 : 3072.0);
     // (measured with 11 words per lane; a block's time goes with its bits)
-    const double t_blk = (nt == 256 ? 21.0 : (nt == 128 ? 28.0 : 41.0)) * (double)blk_segw(k) / 11.0;
+    const double t_blk = (nt == 256 ? 21.0 : (nt == 128 ? 28.0 : 41.0)) * (double)blk_segw_plan(k) / 11.0;
     return (double)(uint64_t)((weighted_blocks + resident - 1.0) / resident) * t_blk;  // whole rounds of the resident grid
 }
 
@@ -753,7 +762,7 @@ void blocks_plan_ragged(Geom &G, const ChunkDesc *d, uint32_t *list_out) {
     const double lanes_us = 0.06 * (double)max_len * (double)((G.total_waves + 98303u) / 98304u);
     if (!(blocks_us_of(wb, nt, G.k) < lanes_us)) return;
     // look-back slots per waveform: enough for the longest one at 25 bits per sample, in blocks of the SMALLEST class's size
-    const uint64_t per = (max_payload_words(max_len) + blk_words(64u, G.k) - 1u) / blk_words(64u, G.k);
+    const uint64_t per = (max_payload_words(max_len) + blk_words_min(64u) - 1u) / blk_words_min(64u);
     if (G.total_waves * per * 12u > (1ull << 30)) return;  // (one very long waveform among very many: the table would not pay)
     G.rag_blocks = 1u;
     G.rag_blk_nt = (uint32_t)nt;
@@ -779,7 +788,7 @@ void blocks_plan_ragged(Geom &G, const ChunkDesc *d, uint32_t *list_out) {
 
 static uint32_t blocks_slots_per_wave(const Geom &G) {  // blocks of a waveform at 25 bits per sample
     if (!G.uniform) return G.rag_blk_slots;
-    const uint64_t per = (max_payload_words(G.u_wave_len) + blk_words(blocks_nt(G), G.k) - 1u) / blk_words(blocks_nt(G), G.k);
+    const uint64_t per = (max_payload_words(G.u_wave_len) + blk_words_min(blocks_nt(G)) - 1u) / blk_words_min(blocks_nt(G));
     return (uint32_t)(per ? per : 1u);
 }
 
@@ -819,17 +828,25 @@ hipError_t launch_decode_blocks(const Geom &G, const uint32_t *d_in, uint64_t in
     if (e != hipSuccess) return e;
     // resident grid: 256 CUs x workgroups per CU (LDS: 51 KB at NT = 256, 26 KB at 128, 13 KB at 64), never more than there are units
     const uint32_t spw = blocks_slots_per_wave(G);
+    // the block geometry of this decode: by the stream's bits per sample as the caller states them (a wrong in_words costs speed, nothing else)
+    const uint64_t b10 = G.total_samples ? 320ull * in_words / G.total_samples : 65ull;
+#ifdef DRX_BLK_FORCE_SW
+    const int sw = DRX_BLK_FORCE_SW;
+#else
+    const int sw = blk_segw_bits10(b10);
+#endif
     auto launch_class = [&](uint32_t cls, const uint32_t *list, uint32_t n_waves, int nt, uint32_t wave_len) {
         uint32_t *info = L.info + 4u * cls;
-        k_blk_max<<<1, 1024, 0, s>>>(n_waves, d_wave_words, blk_words((uint32_t)nt, G.k), info, list);
+        const uint32_t words_per_block = (uint32_t)nt * (uint32_t)sw;
+        k_blk_max<<<1, 1024, 0, s>>>(n_waves, d_wave_words, words_per_block, info, list);
         const uint64_t units = (uint64_t)n_waves * spw;
         // Runs of several blocks only when two runs of one waveform are never in flight together (see the kernel): at least
         // as many waveforms as resident workgroups.  Then as long as the launch keeps kBlkRounds tickets per workgroup (the
         // tail of the last round), up to the whole waveform: only a run's first block waits for other workgroups (nEDM, 6
         // blocks per waveform: one run; NOPTREX, 36: three runs of 12: 1.40 / 0.98 ms against 1.43 / 1.00 with round 2's fixed 4).
         const uint32_t resident = 256u * (nt == 64 ? 12u : (nt == 128 ? 6u : 3u));
-        const uint64_t typ_words = ((uint64_t)wave_len * (2u * G.k + 7u)) >> 6;
-        const uint64_t bpw = (typ_words + blk_words((uint32_t)nt, G.k) - 1u) / blk_words((uint32_t)nt, G.k);
+        const uint64_t typ_words = ((uint64_t)wave_len * b10) / 320u;
+        const uint64_t bpw = (typ_words + words_per_block - 1u) / words_per_block;
         uint64_t rl = ((uint64_t)n_waves * bpw) / ((uint64_t)kBlkRounds * resident);
         rl = rl > bpw ? bpw : rl;
         const uint32_t run_len = n_waves >= resident ? (uint32_t)(rl < 1u ? 1u : rl) : 1u;
@@ -841,7 +858,8 @@ hipError_t launch_decode_blocks(const Geom &G, const uint32_t *d_in, uint64_t in
                                                                info + 2, L.fail, L.suspect, d_status, d_out, L.prof, list, n_waves);
         };
         auto by_sw = [&](auto nt_tag, auto resid_tag, unsigned per_cu) {
-            switch (blk_segw(G.k)) {
+            switch (sw) {
+                case 9: go(nt_tag, resid_tag, std::integral_constant<int, 9>{}, per_cu); break;
                 case 11: go(nt_tag, resid_tag, std::integral_constant<int, 11>{}, per_cu); break;
                 case 15: go(nt_tag, resid_tag, std::integral_constant<int, 15>{}, per_cu); break;
                 default: go(nt_tag, resid_tag, std::integral_constant<int, 19>{}, per_cu); break;

@@ -37,6 +37,7 @@ struct Geom {
     // forward filter in the single-pass encoder: at most 4 taps, any taps[0]; enc_t[j] = taps[j] mod 2^16
     uint32_t enc_fast;
     uint32_t enc_t[4];
+    uint64_t total_samples;  // of the batch
     uint32_t dbg;  // "debug_flags" context option; 0 in normal use.  Dispatch overrides (host side, always available, every
                    // forced path is bit-exact and the tests use them to reach it):
                    //   256 never take the long-waveform paths   512 long waveforms: one workgroup per waveform only

@@ -81,6 +81,10 @@ def collect_traffic(a):
     behind `rocprofv3 ... --` (this process has not touched the GPU yet and never execs).  Returns (kernels, source) or
     (None, why)."""
     import shutil
+    # Under a profiler already (its preloaded library has initialised the GPU in this very process): starting the passes
+    # from here would be an exec behind GPU initialisation, which this pool refuses -- and a profile of a profile anyway.
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process runs under a profiler"
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if not exe:
         return None, "rocprofv3 not found"

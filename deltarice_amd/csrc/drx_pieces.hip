@@ -522,6 +522,68 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
         return P;
     };
 
+    // Samples [s_begin, s_end) of the waveform once more, tile by tile, from bit Bp of the waveform's stream on (their code did
+    // not fit the buffer).  The word in which they start belongs to whoever codes the samples in front; the word in which they
+    // end is completed from the (up to) 32 samples that follow (at least a bit each): wavefronts exchange nothing.  The next
+    // tile's samples travel while this one is coded.
+    auto stream_samples = [&](uint32_t s_begin, uint32_t s_end, uint64_t Bp, uint32_t bits_mine, uint32_t *__restrict__ outp,
+                              uint64_t cap_words) {
+        const uint32_t P0 = (uint32_t)(Bp & 31u);
+        const uint64_t wbase = Bp >> 5;
+        const uint32_t limit = (P0 + bits_mine + 31u) >> 5, skip = P0 ? 1u : 0u;  // words [skip, limit) from wbase are mine
+        const uint32_t more = wf_len - s_end < 32u ? wf_len - s_end : 32u;
+        const uint32_t len = s_end - s_begin + more;
+        for (int i = lane; i < (int)(kEncCapWords + 8) / 4; i += 64) reinterpret_cast<uint4 *>(row)[i] = make_uint4(0, 0, 0, 0);
+        wave_sync();
+        const int16_t *x = in + wf_off + s_begin;
+        uint64_t P = P0;
+        uint32_t cr = 0, cr2 = 0;
+        if (s_begin) {
+            cr = (uint32_t)(uint16_t)x[-1] << 16;
+            if (GEN) {
+                cr |= (uint32_t)(uint16_t)x[-2];
+                cr2 = (uint32_t)(uint16_t)x[-4] | ((uint32_t)(uint16_t)x[-3] << 16);
+            }
+        }
+        uint32_t wn[4];
+        int nvn = load8_dwords(x, len, 0u, lane, true, wn);
+        for (uint32_t t0 = 0; t0 < len; t0 += kTile) {
+            uint32_t w[4] = {wn[0], wn[1], wn[2], wn[3]};
+            const int nv = nvn;
+            if (t0 + kTile < len) nvn = load8_dwords(x, len, t0 + kTile, lane, true, wn);
+            uint32_t xprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[3], 0x138, 0xf, 0xf, false);
+            if (lane == 0) xprev = cr;
+            cr = (uint32_t)__shfl((int)w[3], 63);
+            uint32_t xprev2 = 0;
+            if (GEN) {
+                xprev2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[2], 0x138, 0xf, 0xf, false);
+                if (lane == 0) xprev2 = cr2;
+                cr2 = (uint32_t)__shfl((int)w[2], 63);
+            }
+            PackedCodes pc;
+            packed_codes<GEN>(w, xprev, xprev2, tp, k, pc);
+            mask_tail(pc, nv);
+            const uint32_t lane_bits = lane_tile_bits(pc);
+            const uint32_t incl = wave_incl_scan_dpp(lane_bits);
+            const uint32_t tile_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            const uint64_t wfirst = P >> 5;  // first staged word
+            emit_tile<false>(pc, buf_bits + (uint32_t)(P & 31u) + incl - lane_bits);
+            P += tile_bits;
+            wave_sync();
+            const uint32_t nfull = (uint32_t)((P >> 5) - wfirst);
+            for (uint32_t i = lane; i < nfull; i += 64) {
+                const uint64_t idx = wfirst + i;
+                if (idx >= skip && idx < limit && wbase + idx < cap_words) outp[wbase + idx] = buf[i];
+                buf[i] = 0;
+            }
+            wave_sync();
+            if (nfull && lane == 0) { const uint32_t cwd = buf[nfull]; buf[nfull] = 0; buf[0] = cwd; }
+            wave_sync();
+        }
+        const uint64_t idx = P >> 5;
+        if ((P & 31u) && lane == 0 && idx >= skip && idx < limit && wbase + idx < cap_words) outp[wbase + idx] = buf[0];
+    };
+
     if (runs) {
         const uint32_t words = s_size[wv];
         if (!PACKED && (uint32_t)lane < nspans) wave_words[q.wave_base + w0 + (uint32_t)lane] = s_n[wv][lane];
@@ -554,65 +616,12 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
 #pragma unroll
         for (uint32_t i = 0; i < kPcWaves; ++i) before += i < wv ? s_size[i] : 0u;
         if (!part_fit) {
-            // the part once more, tile by tile, by one wavefront: from bit s_excl_bits of the waveform's stream on; the
-            // word in which it starts belongs to the part in front, the one in which it ends is completed from the 32
-            // samples that follow
-            if (wv != 0u) return;
-            const uint64_t Bp = s_excl_bits;
-            const uint32_t P0 = (uint32_t)(Bp & 31u);
-            const uint64_t wbase = Bp >> 5;
-            const uint32_t limit = (P0 + part_bits + 31u) >> 5, skip = P0 ? 1u : 0u;  // words [skip, limit) from wbase are mine
-            const uint32_t s_begin = part * kPcWaves * sh.seg_len;
-            uint32_t s_end = s_begin + kPcWaves * sh.seg_len;
-            if (s_end > wf_len) s_end = wf_len;
-            const uint32_t more = wf_len - s_end < 32u ? wf_len - s_end : 32u;
-            const uint32_t len = s_end - s_begin + more;
-            for (int i = lane; i < (int)(kEncCapWords + 8) / 4; i += 64) reinterpret_cast<uint4 *>(row)[i] = make_uint4(0, 0, 0, 0);
-            wave_sync();
-            const int16_t *x = in + wf_off + s_begin;
-            uint64_t P = P0;
-            uint32_t cr = 0, cr2 = 0;
-            if (s_begin) {
-                cr = (uint32_t)(uint16_t)x[-1] << 16;
-                if (GEN) {
-                    cr |= (uint32_t)(uint16_t)x[-2];
-                    cr2 = (uint32_t)(uint16_t)x[-4] | ((uint32_t)(uint16_t)x[-3] << 16);
-                }
+            // every wavefront its own segment once more (round 3; one wavefront used to take the whole part: 6 x slower)
+            const uint32_t s_begin = (part * kPcWaves + wv) * sh.seg_len;
+            if (s_begin < wf_len) {
+                const uint32_t s_end = wf_len - s_begin < sh.seg_len ? wf_len : s_begin + sh.seg_len;
+                stream_samples(s_begin, s_end, s_excl_bits + before, s_size[wv], outp, cap_words);
             }
-            for (uint32_t t0 = 0; t0 < len; t0 += kTile) {
-                uint32_t w[4];
-                const int nv = load8_dwords(x, len, t0, lane, true, w);
-                uint32_t xprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[3], 0x138, 0xf, 0xf, false);
-                if (lane == 0) xprev = cr;
-                cr = (uint32_t)__shfl((int)w[3], 63);
-                uint32_t xprev2 = 0;
-                if (GEN) {
-                    xprev2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[2], 0x138, 0xf, 0xf, false);
-                    if (lane == 0) xprev2 = cr2;
-                    cr2 = (uint32_t)__shfl((int)w[2], 63);
-                }
-                PackedCodes pc;
-                packed_codes<GEN>(w, xprev, xprev2, tp, k, pc);
-                mask_tail(pc, nv);
-                const uint32_t lane_bits = lane_tile_bits(pc);
-                const uint32_t incl = wave_incl_scan_dpp(lane_bits);
-                const uint32_t tile_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                const uint64_t wfirst = P >> 5;  // first staged word
-                emit_tile<false>(pc, buf_bits + (uint32_t)(P & 31u) + incl - lane_bits);
-                P += tile_bits;
-                wave_sync();
-                const uint32_t nfull = (uint32_t)((P >> 5) - wfirst);
-                for (uint32_t i = lane; i < nfull; i += 64) {
-                    const uint64_t idx = wfirst + i;
-                    if (idx >= skip && idx < limit && wbase + idx < cap_words) outp[wbase + idx] = buf[i];
-                    buf[i] = 0;
-                }
-                wave_sync();
-                if (nfull && lane == 0) { const uint32_t cwd = buf[nfull]; buf[nfull] = 0; buf[0] = cwd; }
-                wave_sync();
-            }
-            const uint64_t idx = P >> 5;
-            if ((P & 31u) && lane == 0 && idx >= skip && idx < limit && wbase + idx < cap_words) outp[wbase + idx] = buf[0];
             return;
         }
         // my words of the waveform's stream: those whose FIRST bit lies in my segment.  Bits behind my segment come from the
@@ -637,8 +646,12 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
     if (pos + 1u + n > out_cap) return;
     if (sg == 0u && lane == 0) out[pos] = n;
     uint32_t *__restrict__ outp = out + pos + 1u;
-    if (!grp_fit) {
-        if (sg == 0u) stream_waveform(wf_off, wf_len, outp);
+    if (!grp_fit) {  // every wavefront of the group its own segment once more
+        const uint32_t s_begin = sg * sh.seg_len;
+        if (s_begin < wf_len) {
+            const uint32_t s_end = wf_len - s_begin < sh.seg_len ? wf_len : s_begin + sh.seg_len;
+            stream_samples(s_begin, s_end, bits_before, s_size[wv], outp, out_cap - pos - 1u);
+        }
         return;
     }
     // my words of the waveform's stream: those whose FIRST bit lies in my segment

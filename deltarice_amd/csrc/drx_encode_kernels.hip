@@ -584,9 +584,12 @@ __global__ __launch_bounds__(64 * WV, DRX_ENC_WAVES_PER_EU) void k_encode_fused(
     P = 0;
     carry = 0;
     carry2 = 0;
+    uint32_t wn[4];
+    int nvn = r.len ? load8_dwords(x, r.len, 0u, lane, vec_ok, wn) : 0;
     for (uint32_t t0 = 0; t0 < r.len; t0 += kTile) {
-        uint32_t w[4];
-        const int nv = load8_dwords(x, r.len, t0, lane, vec_ok, w);
+        uint32_t w[4] = {wn[0], wn[1], wn[2], wn[3]};
+        const int nv = nvn;
+        if (t0 + kTile < r.len) nvn = load8_dwords(x, r.len, t0 + kTile, lane, vec_ok, wn);  // (travels while this tile is coded)
         uint32_t xprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[3], 0x138, 0xf, 0xf, false);
         if (lane == 0) xprev = carry;
         carry = (uint32_t)__shfl((int)w[3], 63);

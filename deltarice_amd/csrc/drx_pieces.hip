@@ -490,9 +490,12 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
         const int16_t *x = in + soff;
         uint64_t P = 0;
         uint32_t cr = 0, cr2 = 0;
+        uint32_t wn[4];
+        int nvn = load8_dwords(x, len, 0u, lane, true, wn);
         for (uint32_t t0 = 0; t0 < len; t0 += kTile) {
-            uint32_t w[4];
-            const int nv = load8_dwords(x, len, t0, lane, true, w);
+            uint32_t w[4] = {wn[0], wn[1], wn[2], wn[3]};
+            const int nv = nvn;
+            if (t0 + kTile < len) nvn = load8_dwords(x, len, t0 + kTile, lane, true, wn);  // (travels while this tile is coded)
             uint32_t xprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[3], 0x138, 0xf, 0xf, false);
             if (lane == 0) xprev = cr;
             cr = (uint32_t)__shfl((int)w[3], 63);

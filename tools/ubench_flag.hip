@@ -17,14 +17,21 @@ __device__ __forceinline__ uint32_t xcc_id() {
     return v & 0xfu;
 }
 
-template <int SCOPE>  // 0: agent scope, 1: workgroup scope (L2 of the XCD: only meaningful when both sit on one XCD)
+// 0: agent scope, 1: workgroup scope, 2: polls through the SCALAR cache with glc (stores agent scope) -- the scalar path does
+// not queue behind a CU's vector memory traffic (round 1: the header walkers), but is it coherent?
+template <int SCOPE>
 __device__ __forceinline__ uint32_t ld(const uint32_t *p) {
+    if (SCOPE == 2) {
+        uint32_t v;
+        asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+        return v;
+    }
     return SCOPE == 0 ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                       : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 template <int SCOPE>
 __device__ __forceinline__ void st(uint32_t *p, uint32_t v) {
-    if (SCOPE == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (SCOPE == 0 || SCOPE == 2) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
@@ -78,6 +85,8 @@ int main() {
         {"agent scope, workgroups 0 and 8 (one XCD)", 0, 0, 8, 16},
         {"workgroup scope, workgroups 0 and 8 (one XCD)", 1, 0, 8, 16},
         {"workgroup scope, workgroups 0 and 1 (two XCDs: may never arrive)", 1, 0, 1, 16},
+        {"scalar glc polls, workgroups 0 and 8 (one XCD)", 2, 0, 8, 16},
+        {"scalar glc polls, workgroups 0 and 1 (two XCDs)", 2, 0, 1, 16},
     };
     for (const Case &c : cases) {
         CHECK(hipMemset(flags, 0, 4096));
@@ -87,7 +96,8 @@ int main() {
         CHECK(hipEventCreate(&e1));
         CHECK(hipEventRecord(e0));
         if (c.scope == 0) k_pingpong<0><<<c.grid, 64>>>(flags, xcc, c.a, c.b, iters, cycles, timeouts);
-        else k_pingpong<1><<<c.grid, 64>>>(flags, xcc, c.a, c.b, iters, cycles, timeouts);
+        else if (c.scope == 1) k_pingpong<1><<<c.grid, 64>>>(flags, xcc, c.a, c.b, iters, cycles, timeouts);
+        else k_pingpong<2><<<c.grid, 64>>>(flags, xcc, c.a, c.b, iters, cycles, timeouts);
         CHECK(hipEventRecord(e1));
         CHECK(hipDeviceSynchronize());
         float ms = 0;
@@ -101,18 +111,19 @@ int main() {
         printf("%-68s XCC %u / %u: %s%.0f ns per round trip (two hops; %.3f ms for %u)\n", c.name, hx[c.a], hx[c.b],
                lost ? "TIMED OUT, " : "", lost ? 0.0 : ms * 1e6 / iters, ms, iters);
     }
-    for (int scope = 0; scope < 2; ++scope) {
+    for (int scope = 0; scope < 3; ++scope) {
         hipEvent_t e0, e1;
         CHECK(hipEventCreate(&e0));
         CHECK(hipEventCreate(&e1));
         CHECK(hipEventRecord(e0));
         if (scope == 0) k_poll<0><<<1, 64>>>(flags, 20000, cycles, sink);
-        else k_poll<1><<<1, 64>>>(flags, 20000, cycles, sink);
+        else if (scope == 1) k_poll<1><<<1, 64>>>(flags, 20000, cycles, sink);
+        else k_poll<2><<<1, 64>>>(flags, 20000, cycles, sink);
         CHECK(hipEventRecord(e1));
         CHECK(hipDeviceSynchronize());
         float ms = 0;
         CHECK(hipEventElapsedTime(&ms, e0, e1));
-        printf("a dependent poll of an idle word, %s scope: %.0f ns\n", scope == 0 ? "agent" : "workgroup", ms * 1e6 / 20000);
+        printf("a dependent poll of an idle word, %s scope: %.0f ns\n", scope == 0 ? "agent" : (scope == 1 ? "workgroup" : "scalar glc,"), ms * 1e6 / 20000);
     }
     printf("XCC ids of workgroups 0..15:");
     std::vector<uint32_t> hx(16);

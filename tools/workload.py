@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--m", type=int, default=8)
     ap.add_argument("--sigma", type=float, default=10.0, help="standard deviation of the Gaussian samples")
+    ap.add_argument("--ramp", action="store_true", help="a slope-1 sawtooth instead of noise (a DAQ's test pattern: codes of one length, "
+                    "a speculative parse never falls into step)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--debug-flags", type=int, default=0)
     ap.add_argument("--sideband", action="store_true", help="decode with the encoder's n_i table as a side-band (drx_decode_with_wave_words)")
@@ -93,7 +95,10 @@ def main():
     slab = 1 << 28
     for s0 in range(0, total, slab):
         n = min(slab, total - s0)
-        x[s0:s0 + n] = (torch.randn(n, device=ctx.device, generator=g) * a.sigma).to(torch.int16)
+        if a.ramp:
+            x[s0:s0 + n] = ((torch.arange(s0, s0 + n, device=ctx.device) % 60000) - 30000).to(torch.int16)
+        else:
+            x[s0:s0 + n] = (torch.randn(n, device=ctx.device, generator=g) * a.sigma).to(torch.int16)
     uniform = len(set(Ns)) == 1 and len(set(Ls)) == 1
     taps = FIR4 if a.name.endswith("_fir4") else None
     if uniform:

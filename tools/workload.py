@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--m", type=int, default=8)
     ap.add_argument("--sigma", type=float, default=10.0, help="standard deviation of the Gaussian samples")
+    ap.add_argument("--pulses", action="store_true", help="detector-like data: a quiet baseline (--sigma) with a pulse of amplitude 2000 and "
+                    "200 samples of exponential decay every 7000 samples")
     ap.add_argument("--ramp", action="store_true", help="a slope-1 sawtooth instead of noise (a DAQ's test pattern: codes of one length, "
                     "a speculative parse never falls into step)")
     ap.add_argument("--no-verify", action="store_true")
@@ -95,7 +97,12 @@ def main():
     slab = 1 << 28
     for s0 in range(0, total, slab):
         n = min(slab, total - s0)
-        if a.ramp:
+        if a.pulses:
+            i = torch.arange(s0, s0 + n, device=ctx.device)
+            t = (i % 7000 - 1000).to(torch.float32)
+            pulse = torch.where(t >= 0, 2000.0 * torch.exp(-t.clamp(min=0) / 200.0), torch.zeros_like(t))
+            x[s0:s0 + n] = (torch.randn(n, device=ctx.device, generator=g) * a.sigma + pulse).to(torch.int16)
+        elif a.ramp:
             x[s0:s0 + n] = ((torch.arange(s0, s0 + n, device=ctx.device) % 60000) - 30000).to(torch.int16)
         else:
             x[s0:s0 + n] = (torch.randn(n, device=ctx.device, generator=g) * a.sigma).to(torch.int16)

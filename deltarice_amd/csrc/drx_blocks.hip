@@ -141,6 +141,11 @@ enum { kBlkSkip = 0, kBlkCount = 1, kBlkValue = 2 };
 // count-leading-zeros that is defined for 0: v_ffbh_u32 returns -1 there, which with the escape's 16 payload bits moves the
 // parse on by 15 + 1 bits -- any progress will do (an all-zero window is the padding behind a waveform or a corrupt stream)
 __device__ __forceinline__ uint32_t clz_nz(uint32_t x) { return ffbh(x); }
+// the 32 bits at Qp of a block's image (see blk_pair)
+__device__ __forceinline__ uint32_t blk_window(const uint32_t *W, uint32_t Qp) {
+    const uint32_t idx = Qp >> 5;
+    return __builtin_amdgcn_alignbit(W[idx + 2u], W[idx + 1u], Qp);
+}
 
 // Two codes from the 64-bit window at Qp (three words: a 64-bit window always holds two codes of at most 25 bits).
 // W: the block's LDS image; word w of the image sits at W[K + 1 - w] and Qp = 32 K - (bit position), so that
@@ -337,6 +342,8 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
     // tickets: every lower ticket is held by a running (or finished) workgroup, so waiting for a predecessor cannot
     // deadlock whatever the dispatch order; the grid is sized to be resident
     uint32_t &s_next = s_e[NT + 2 * NW + 6];
+    uint32_t &s_front = s_e[NT + 2 * NW + 7];   // settle(): the lowest lane that started again last round and how far its end moved
+    uint32_t &s_defer = s_e[NT + 2 * NW + 11];  // this block does not publish its end before its start is verified
     uint32_t *const s_vote = s_e + NT + 2 * NW + 8;  // [3], in rotation, so that a vote needs one barrier
     uint32_t vote_no = 0;
     // true in every thread if `v` holds in any thread of the workgroup.  Vote i uses word i mod 3; thread 0 clears the word
@@ -448,6 +455,7 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
             const uint32_t avail = (n - w0 < BG::kWords) ? n - w0 : BG::kWords;
             const uint32_t s_i0 = (uint32_t)((int64_t)(pay_lo + w0) - image_base(pay_lo, blk));  // image index of the block's first word
             store_image(cur, blk, img);
+            if (tid == 0) s_defer = 0u;
             blk_barrier();
             BLK_STAMP(1);  // image
 
@@ -473,26 +481,76 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
             uint32_t e = C - Qp;  // first code that starts behind it (or where the padding starts)
             BLK_STAMP(2);  // run-up + count (thread 0's wave)
 
-            // every lane must start where its predecessor ended; lanes that do not, start again from there
+            // Every lane must start where its predecessor ended; lanes that do not, start again from there.
+            // CREEP: in a stream of equal-length codes whose pattern reads as the same codes from another phase (a slope-1 ramp
+            // is "1010" per sample) a parse never falls into step: lanes that guessed the same wrong phase agree with one
+            // another, and once lane 0 is put right the correction moves ONE lane per round (243 rounds per block measured,
+            // NOPTREX-shaped ramps 81 ms).  Its signature -- the lowest lane that starts again advances by exactly one per
+            // round and its end moves by the same amount each time -- is looked for, and after three such rounds every lane
+            // behind the front is shifted by that amount at once.  Only where to start again is guessed (at most four times per
+            // call); what is accepted is still the chain of equalities.  Noise and quiet data never show the signature.
             auto settle = [&]() __attribute__((always_inline)) {
-                for (uint32_t it = 0; it <= (uint32_t)NT; ++it) {
+                uint32_t prev_front = 0xffffffffu, creep = 0, jumps = 0;
+                if (tid == 0) s_front = 0xffffffffu;
+                for (uint32_t it = 0; it <= 2u * (uint32_t)NT + 8u; ++it) {
                     s_e[tid] = e;
                     blk_barrier();
                     const uint32_t want = tid ? s_e[tid - 1u] : f;
-                    const bool changed = active && want != f;
-                    if (!wg_any(changed)) break;  // (also: every read of s_e is done before the next write)
-                    if (changed) { f = want; Qp = C - f; cnt = 0; sum = 0; }
+                    bool changed = active && want != f;
+                    uint32_t from = want;
+                    const uint32_t front = s_front;  // (lane << 8) | (how far its end moved + 128), 0xffffffff: nobody started again
+                    if (it > 0u) {
+                        const bool step = front != 0xffffffffu && prev_front != 0xffffffffu && (front >> 8) == (prev_front >> 8) + 1u &&
+                                          (front & 0xffu) == (prev_front & 0xffu) && (front & 0xffu) != 128u && (front & 0xffu) != 0u;
+                        creep = step ? creep + 1u : 0u;
+                        prev_front = front;
+                        if (creep >= 2u && jumps < 4u) {
+                            creep = 0;
+                            ++jumps;
+                            prev_front = 0xffffffffu;
+                            const uint32_t to = f + (front & 0xffu) - 128u;
+                            if (active && tid > (front >> 8) && (int32_t)(to - bj) >= 0 && to < lim) { from = to; changed = from != f; }
+                        }
+                    }
+                    if (!wg_any(changed)) break;  // (also: every read of s_e and s_front is done before the next write)
+                    if (tid == 0) s_front = 0xffffffffu;
+                    blk_barrier();
+                    const uint32_t e_old = e;
+                    if (changed) { f = from; Qp = C - f; cnt = 0; sum = 0; }
                     blk_parse<kBlkCount, RESID>(W, k, changed, Qp, C - lim, cnt, sum, 0u, nullptr, my_stage, qpad, kCap2);
-                    if (changed) e = C - Qp;
+                    if (changed) {
+                        e = C - Qp;
+                        const int32_t d = (int32_t)(e - e_old);
+                        const uint32_t dd = (d > -128 && d < 128) ? (uint32_t)(d + 128) : 0u;
+                        __hip_atomic_fetch_min(&s_front, (tid << 8) | dd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 }
             };
+            // A block whose lane 0 only guessed its start and reads a pattern that another phase reads as the same codes does
+            // not publish its end before its predecessor's has confirmed the guess: the end would move, and a successor that
+            // started from it sends the whole waveform to the one-workgroup fallback (ramps: 25 x 14 M samples 824 ms).
+            // (asked of lane 0, whose guess decides whether the block has to start again, and of the last lane, whose end is the one published)
+            if (first_of_run && blk > 0u && cnt >= 8u && (tid == 0u || tid == (avail + (uint32_t)kBlkSegW - 1u) / (uint32_t)kBlkSegW - 1u)) {
+                bool amb = false;
+                const BlkPair p0 = blk_pair<false>(W, k, C - f);
+                const uint32_t f2 = f + (0u - p0.nu1), P = 0u - p0.nu2;  // (nu = minus the code length; from the second code on)
+                if (P != 0u && P < 26u && P * (cnt - 1u) == e - f2) {  // codes of one length ...
+                    const uint32_t w0 = blk_window(W, C - f2);
+                    if (w0 == blk_window(W, C - (f2 + P)) && w0 == blk_window(W, C - (f2 + 2u * P))) {  // ... of one pattern ...
+                        for (uint32_t r = 1; r < P && !amb; ++r)  // ... that reads as a code of that length from another phase
+                            amb = (0u - blk_pair<false>(W, k, C - (f2 + r)).nu1) == P;
+                    }
+                }
+                if (amb) s_defer = 1u;
+            }
             settle();
+            const bool defer = s_defer != 0u;  // (read behind settle()'s barriers)
             BLK_STAMP(3);  // settle (includes waiting for the slowest wave)
             const uint32_t last_active = (avail + (uint32_t)kBlkSegW - 1u) / (uint32_t)kBlkSegW - 1u;
             const uint32_t e_last0 = s_e[last_active];
             const bool last_of_run = blk + 1u == blk_hi;
             // the end of this run = the start of the next one, published as soon as it is known
-            if (tid == 0 && last_of_run)
+            if (tid == 0 && last_of_run && !defer)
                 __hip_atomic_store(ends + sidx, 0x80000000u | (e_last0 - bend), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (first_of_run && blk > 0) {
                 if (tid == 0) {
@@ -515,8 +573,10 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
                     settle();
                     // a one-block run has published its end already, and its successor has started from it: if that end
                     // moved, the successor's run is wrong
-                    if (tid == 0 && last_of_run && s_e[last_active] != e_last0 && blk + 1u < n_blocks) atomicExch(fail + g, 1u);
+                    if (tid == 0 && last_of_run && !defer && s_e[last_active] != e_last0 && blk + 1u < n_blocks) atomicExch(fail + g, 1u);
                 }
+                if (tid == 0 && last_of_run && defer)
+                    __hip_atomic_store(ends + sidx, 0x80000000u | (s_e[last_active] - bend), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             const uint32_t e_end = s_e[last_active];  // (after a correction: the corrected end)
             BLK_STAMP(4);  // predecessor's end

@@ -119,3 +119,27 @@ def test_pieces_encoder_sizes_follow_the_rice_parameter(ctx, O):
             N = W * L - L // 3
             x = noise(rng, sigma, n_chunks * N)
             check(ctx, O, x, n_chunks, N, (m, L), enc_flags=(0, 8192), dec_flags=(0,))
+
+
+def test_streams_of_equal_length_codes(ctx, O):
+    """Ramps and square waves code every sample alike ("1010" for slope 1), and a parse from another phase reads the same
+    codes: the block decoder's lanes agree with one another on a wrong phase.  The correction is found as a creep (one lane
+    per settle round) and applied to all lanes at once, and a block that reads such a pattern does not publish its end before
+    its start is verified (drx_blocks.hip: settle()).  Sawtooth wraps put escapes in between; every case must still be the
+    oracle's samples, through the block decoder and through the lanes."""
+    n = 3 * 300000
+    i = np.arange(n)
+    cases = {
+        "slope 1 sawtooth": (i % 60000 - 30000),
+        "slope -1 sawtooth": (30000 - i % 60000),
+        "slope 2 sawtooth": (2 * (i % 30000) - 30000),
+        "slope 3, short period": (3 * (i % 700) - 1000),
+        "square wave": np.where((i // 50) % 2 == 0, 100, -100),
+        "alternating +-1": np.where(i % 2 == 0, 7, 8),
+        "ramp with noise stretches": np.where((i // 40000) % 3 == 0, np.random.default_rng(46).normal(0, 10, n), i % 60000 - 30000),
+    }
+    for name, v in cases.items():
+        x = np.ascontiguousarray(v).astype(np.int16)
+        for L, m in ((300000, 8), (100000, 8), (300000, 64)):
+            N = 300000
+            check(ctx, O, x, 3, N, (m, L), want_blocks=True)

@@ -566,10 +566,19 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
                 blk_barrier();
                 const uint32_t true_f0 = B0 + s_pred;
                 const bool fix0 = tid == 0 && true_f0 != f;
+                if (fix0) s_next = true_f0 - f;  // (how far lane 0 moves; s_next is not in use here)
                 if (wg_any(fix0)) {
-                    if (fix0) { f = true_f0; Qp = C - f; cnt = 0; sum = 0; }
-                    blk_parse<kBlkCount, RESID>(W, k, fix0, Qp, C - lim, cnt, sum, 0u, nullptr, my_stage, qpad, kCap2);
-                    if (fix0) e = C - Qp;
+                    // a block that held its end back reads one pattern throughout: its lanes all guessed the phase lane 0 guessed,
+                    // and move with it (a guess again: settle() below accepts nothing but the chain of equalities)
+                    bool mv = fix0;
+                    uint32_t to = true_f0;
+                    if (defer && tid != 0u && active) {
+                        const uint32_t t = f + s_next;
+                        if ((int32_t)(t - bj) >= 0 && t < lim) { mv = true; to = t; }
+                    }
+                    if (mv) { f = to; Qp = C - f; cnt = 0; sum = 0; }
+                    blk_parse<kBlkCount, RESID>(W, k, mv, Qp, C - lim, cnt, sum, 0u, nullptr, my_stage, qpad, kCap2);
+                    if (mv) e = C - Qp;
                     settle();
                     // a one-block run has published its end already, and its successor has started from it: if that end
                     // moved, the successor's run is wrong

@@ -17,7 +17,7 @@ import deltarice_amd as dr  # noqa: E402
 
 
 def run_bench(extra):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-seconds", "0", "--steps", "3",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-seconds", "0", "--no-collect", "--steps", "3",
                           "--warmup", "1"] + extra, capture_output=True, text=True, check=True).stdout
     return json.loads(out.strip().splitlines()[-1])
 

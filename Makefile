@@ -12,7 +12,7 @@ HIPFLAGS  ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-funct
 CSRC      := deltarice_amd/csrc
 HIP_LIB   := deltarice_amd/libdeltarice_hip.so
 PLUGIN    := deltarice_amd/plugin/libh5deltarice.so
-HIP_SRCS  := $(CSRC)/drx_encode_kernels.hip $(CSRC)/drx_decode_kernels.hip $(CSRC)/drx_blocks.hip $(CSRC)/drx_pieces.hip $(CSRC)/drx_iir.hip $(CSRC)/drx_api.hip
+HIP_SRCS  := $(CSRC)/drx_encode_kernels.hip $(CSRC)/drx_encode_stream.hip $(CSRC)/drx_decode_kernels.hip $(CSRC)/drx_blocks.hip $(CSRC)/drx_pieces.hip $(CSRC)/drx_iir.hip $(CSRC)/drx_api.hip
 HIP_OBJS  := $(HIP_SRCS:.hip=.o)
 HIP_HDRS  := $(CSRC)/drx_internal.h $(CSRC)/drx_device.h $(CSRC)/drx_encode.h $(CSRC)/drx_walk.h include/deltarice_hip.h
 
@@ -57,14 +57,19 @@ $(H5IO): $(CSRC)/h5_direct.c include/deltarice_h5io.h include/deltarice_hip.h $(
 
 # deltaRice/h5.pyx -> deltaRice/h5.cpython-*.so, linked against the plugin library (whose callback runs the HIP codec).
 # h5py is needed to IMPORT the module, not to build it.
-# Best effort inside `all`: a box without cython or the Python headers still builds the codec library and the plugin
-# (`make pyext-strict` fails loudly instead).
+# A box without cython or the Python headers fails `make all` loudly (the drop-in module would be missing from a build that
+# exits 0); `make SKIP_PYEXT=1` builds the codec library and the plugin without it.
 HAVE_PYEXT_TOOLS := $(shell command -v $(CYTHON) >/dev/null 2>&1 && [ -f "$(PY_INC)/Python.h" ] && echo yes)
 ifeq ($(HAVE_PYEXT_TOOLS),yes)
 pyext: $(PYEXT)
 else
 pyext:
-	@echo "pyext: skipped ($(CYTHON) or $(PY_INC)/Python.h not found); deltaRice.h5 needs it, the codec and the HDF5 plugin do not"
+ifeq ($(SKIP_PYEXT),1)
+	@echo "pyext: skipped (SKIP_PYEXT=1; $(CYTHON) or $(PY_INC)/Python.h not found); deltaRice.h5 needs it, the codec and the HDF5 plugin do not"
+else
+	@echo "pyext: $(CYTHON) or $(PY_INC)/Python.h not found -- the reference's Python surface (deltaRice.h5) cannot be built."; \
+	 echo "       \`make SKIP_PYEXT=1\` builds the codec library and the HDF5 plugin without it."; exit 1
+endif
 endif
 .PHONY: pyext-strict
 pyext-strict: $(PYEXT)

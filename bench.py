@@ -403,6 +403,9 @@ def main():
                           "decode_prepare": float(dec_ms[0]), "decode_kernel": float(dec_ms[1])},
             "roofline": {"bound": "hbm", "kernel": "k_decode_lanes", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         # true: the two rocprofv3 --pmc child passes ran in this session BEFORE the timed region (A/B scripts
+                         # pass --no-collect; profiles/r04_notes.md has both forms measured on one box)
+                         "traffic_collected_in_run": traffic_kernels is not None,
                          "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": dec_kernel_ms},
             "roofline_encode": {"bound": "hbm", "kernel": "k_encode_fused", "achieved": algo_bytes / (pack_ms * 1e-3) / 1e9,
                                 "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -29,7 +29,8 @@ struct drx_ctx {
     int decode_impl = 8;   // launch_decode(): 8 = walk fused into the staged kernel, two samples per ring access
                            // (default), 7 = the same with a separate walk kernel, 5 / 1 = one sample per ring access
                            // (fused / separate walk), 0 = simple kernel
-    int encode_impl = 1;  // 1: single pass with look-back (k_encode_fused), 0: size pass + scan + pack pass
+    int encode_impl = 2;  // 2: single pass, persistent (k_encode_stream) where the standard geometry applies; 1: single pass with
+                          // look-back (k_encode_fused) everywhere; 0: size pass + scan + pack pass
     int profile = 0;      // bracket kernels with HIP events (drx_plan_last_timings)
     uint32_t debug_flags = 0;  // Geom::dbg
     std::string last_error;
@@ -241,7 +242,7 @@ drx_status drx_ctx_set_option(drx_ctx *c, const char *key, int64_t value) {
         return DRX_OK;
     }
     if (!strcmp(key, "encode_impl")) {
-        if (value < 0 || value > 1) return DRX_ERR_ARG;
+        if (value < 0 || value > 2) return DRX_ERR_ARG;
         c->encode_impl = (int)value;
         return DRX_OK;
     }
@@ -291,7 +292,8 @@ static drx_status plan_alloc(drx_ctx *ctx, drx_plan *p) {  // (callers hold the 
     DRX_HIP(ctx, hipMalloc((void **)&p->d_wave_rel, W * sizeof(uint32_t)));
     DRX_HIP(ctx, hipMalloc((void **)&p->d_wave_off, W * sizeof(uint64_t)));
     DRX_HIP(ctx, hipMalloc((void **)&p->d_chunk_words, (p->G.n_chunks + 1) * sizeof(uint64_t)));
-    DRX_HIP(ctx, hipMalloc((void **)&p->d_scan, (W + 18) * sizeof(uint64_t)));
+    DRX_HIP(ctx, hipMalloc((void **)&p->d_scan, (2 * W + 18) * sizeof(uint64_t)));  // (k_encode_stream: size[W] | place[W] | control)
+    DRX_HIP(ctx, hipMemset(p->d_scan, 0, (2 * W + 18) * sizeof(uint64_t)));
     DRX_HIP(ctx, hipMalloc((void **)&p->d_status, sizeof(DevStatus)));
     DRX_HIP(ctx, hipHostMalloc((void **)&p->h_status, sizeof(DevStatus), hipHostMallocDefault));
     memset(p->h_status, 0, sizeof(DevStatus));
@@ -586,10 +588,11 @@ drx_status drx_encode(drx_plan *p, const int16_t *d_in, uint32_t *d_out, uint64_
     DRX_ON_DEVICE(ctx);
     DRX_HIP(ctx, hipMemsetAsync(p->d_status, 0, sizeof(DevStatus), ctx->stream));
     p->G.dbg = ctx->debug_flags;
-    if (ctx->encode_impl == 1 && p->d_pc_scan && pieces_batch(p->G)) {
+    const bool single = ctx->encode_impl >= 1;
+    if (single && p->d_pc_scan && pieces_batch(p->G)) {
         DRX_HIP(ctx, launch_encode_pieces(p->G, d_in, p->total_samples, d_out, out_cap_words, d_chunk_word_off, p->d_wave_words,
                                           p->d_pc_scan, p->pc_wgs, p->d_status, ctx->profile ? p->ev : nullptr, ctx->stream));
-    } else if (ctx->encode_impl == 1 && long_batch(p->G) && !(ctx->debug_flags & 256u)) {
+    } else if (single && long_batch(p->G) && !(ctx->debug_flags & 256u)) {
         if (!p->d_seg_bits) {  // only when a diagnostic debug_flags value forces this path on a geometry that does not take it
             const uint64_t units = long_batch_units(p->G);
             DRX_HIP(ctx, hipMalloc((void **)&p->d_seg_bits, units * sizeof(uint32_t)));
@@ -598,7 +601,10 @@ drx_status drx_encode(drx_plan *p, const int16_t *d_in, uint32_t *d_out, uint64_
         DRX_HIP(ctx, launch_encode_long(p->G, d_in, d_out, out_cap_words, d_chunk_word_off, p->d_wave_words, p->d_wave_rel,
                                         p->d_chunk_words, p->d_seg_bits, p->d_seg_pos, p->d_status,
                                         ctx->profile ? p->ev : nullptr, ctx->stream));
-    } else if (ctx->encode_impl == 1 && (p->G.n_taps == 0 || p->G.enc_fast))
+    } else if (ctx->encode_impl == 2 && (p->G.n_taps == 0 || p->G.enc_fast) && fused_wide(p->G) == 0)
+        DRX_HIP(ctx, launch_encode_stream(p->G, d_in, d_out, out_cap_words, d_chunk_word_off, p->d_wave_words,
+                                          p->d_scan, p->d_status, ctx->profile ? p->ev : nullptr, ctx->stream));
+    else if (single && (p->G.n_taps == 0 || p->G.enc_fast))
         DRX_HIP(ctx, launch_encode_fused(p->G, d_in, d_out, out_cap_words, d_chunk_word_off, p->d_wave_words,
                                          p->d_scan, p->d_status, ctx->profile ? p->ev : nullptr, ctx->stream));
     else

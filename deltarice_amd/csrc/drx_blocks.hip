@@ -909,8 +909,9 @@ hipError_t launch_decode_blocks(const Geom &G, const uint32_t *d_in, uint64_t in
         const uint32_t words_per_block = (uint32_t)nt * (uint32_t)sw;
         k_blk_max<<<1, 1024, 0, s>>>(n_waves, d_wave_words, words_per_block, info, list);
         const uint64_t units = (uint64_t)n_waves * spw;
-        // Runs of several blocks only when two runs of one waveform are never in flight together (see the kernel): at least
-        // as many waveforms as resident workgroups.  Then as long as the launch keeps kBlkRounds tickets per workgroup (the
+        // Runs of several blocks only when two runs of one waveform are RARELY in flight together (see the kernel): at least
+        // as many waveforms as resident workgroups.  (Ticket order does not exclude it -- a slow workgroup holding ticket t may
+        // still run when ticket t + n_waves is drawn; the later run's look-back then simply waits on the lower ticket.)  Then as long as the launch keeps kBlkRounds tickets per workgroup (the
         // tail of the last round), up to the whole waveform: only a run's first block waits for other workgroups (nEDM, 6
         // blocks per waveform: one run; NOPTREX, 36: three runs of 12: 1.40 / 0.98 ms against 1.43 / 1.00 with round 2's fixed 4).
         const uint32_t resident = 256u * (nt == 64 ? 12u : (nt == 128 ? 6u : 3u));

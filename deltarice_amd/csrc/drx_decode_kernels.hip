@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void k_sideband_tables(Geom G, const uint32_t 
                                                          const uint64_t *__restrict__ chunk_word_off,
                                                          const uint32_t *__restrict__ n_in, uint64_t *__restrict__ wave_off,
                                                          uint32_t *__restrict__ wave_words, DevStatus *st) {
-    __shared__ uint32_t wsum[4];
+    __shared__ uint64_t wsum[4];
     const uint64_t c = blockIdx.x;
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     uint64_t base;
@@ -41,31 +41,43 @@ __global__ __launch_bounds__(256) void k_sideband_tables(Geom G, const uint32_t 
     if (G.uniform) { base = c * G.u_n_waves; W = G.u_n_waves; L = G.u_wave_len; N = G.u_n_samples; }
     else { const ChunkDesc d = G.chunks[c]; base = d.wave_base; W = d.n_waves; L = d.wave_len; N = d.n_samples; }
     const uint64_t off0 = chunk_word_off[c], off1 = chunk_word_off[c + 1];
-    bool bad = off1 > in_words || off0 >= off1;
+    bool bad = off1 > in_words || off0 >= off1;  // (the same in every lane here; block-wide after every round below)
     uint64_t run = 1;  // the chunk header word
     for (uint32_t i0 = 0; i0 < W; i0 += 256) {
         const uint32_t i = i0 + threadIdx.x;
         const uint32_t n = (i < W) ? n_in[base + i] : 0u;
-        const uint32_t v = (i < W) ? n + 1u : 0u;
-        const uint32_t inc = wave_incl_scan_u32(v, lane);
+        const uint32_t len = (i < W) ? ((i + 1u == W) ? N - i * L : L) : 0u;
+        // An entry outside the bounds of its waveform never enters the prefix sum (64-bit: 256 entries of up to 25 bits per
+        // sample of a 2^31-sample waveform do not fit 32), so no later position can wrap below off0 or past 2^64; and the
+        // whole chunk is rejected before any lane looks at the stream.
+        const bool n_ok = i >= W || (n <= max_payload_words(len) && n >= min_payload_words(len, G.k));
+        const uint64_t v = (i < W && n_ok) ? (uint64_t)n + 1u : 0u;
+        uint64_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t t = __shfl_up(inc, d);
+            if (lane >= d) inc += t;
+        }
         if (lane == 63) wsum[wv] = inc;
-        __syncthreads();
-        uint32_t before = 0, all = 0;
+        bad = __syncthreads_or(bad || !n_ok) != 0;
+        uint64_t before = 0, all = 0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) { before += (w < wv) ? wsum[w] : 0u; all += wsum[w]; }
+        bool mine_bad = bad;
         if (i < W) {
             const uint64_t at = off0 + run + before + inc - v;
-            const uint32_t len = (i + 1u == W) ? N - i * L : L;
-            if (n > max_payload_words(len) || n < min_payload_words(len, G.k) || at + 1u + n > off1 || bad) bad = true;
-            else if (in[at] != n) bad = true;
-            wave_off[base + i] = bad ? off0 : at;  // (a rejected table is never dereferenced: the launch behind this is skipped on error)
-            wave_words[base + i] = bad ? 0u : n;
+            if (!mine_bad && (at <= off0 || at >= off1 || at + 1u + n > off1)) mine_bad = true;
+            if (!mine_bad && in[at] != n) mine_bad = true;
+            // a rejected entry is left pointing at the chunk's own header with no payload words: the decode launch behind
+            // this one runs whatever the status says, and reads nothing through such an entry
+            wave_off[base + i] = mine_bad ? off0 : at;
+            wave_words[base + i] = mine_bad ? 0u : n;
         }
         run += all;
-        __syncthreads();
+        bad = __syncthreads_or(mine_bad) != 0;  // (also keeps wsum until every lane has read it)
     }
     if (threadIdx.x == 0 && !bad && (off0 + run != off1 || in[off0] != N)) bad = true;
-    if (bad) atomicOr(&st->err, kErrCorrupt);
+    if (bad && threadIdx.x == 0) atomicOr(&st->err, kErrCorrupt);
 }
 
 // Straightforward lane-per-waveform decoder: global loads and 2-byte stores.

@@ -15,6 +15,8 @@
 // (The packed tile code: drx_encode.h; short and very long waveforms: drx_pieces.hip.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -323,6 +325,25 @@ constexpr int kLbWin = DRX_ENC_LB_WIN;  // look-back window of k_encode_fused in
 // sample, and a waveform whose code outgrows its buffer is coded twice -- 8 x 2496 (two workgroups per CU), 4 x 3072 (three)
 // and 4 x 4096 words (two) keep the single pass for it (fused_wide(), drx_internal.h).  Six waveforms per workgroup were
 // measured a third slower whatever the buffer (three of them on two SIMDs, one each on the others).
+// Diagnostic build (-DDRX_ENC_STAMPS, never shipped): lane 0 of every workgroup's wave 0 adds the 100 MHz ticks between the
+// phases of k_encode_fused into eight counters behind the look-back state; launch_encode_fused prints the shares.
+//   0 encode (start -> all eight waveforms coded)   1 gate (nearest predecessor has published ANYTHING)
+//   2 window (a prefix found behind it)   3 copy-out of wave 0
+#ifdef DRX_ENC_STAMPS
+// (a slot per workgroup in the upper half of the look-back state, which k_encode_fused does not use: atomics on eight shared
+// counters ran at the rate of one counter -- ~88 per microsecond -- and turned a 5.5 ms kernel into an 8 ms one)
+#define ENC_STAMP(i)                                                                        \
+    do {                                                                                    \
+        if (threadIdx.x == 0) {                                                             \
+            const uint64_t t_now = __builtin_amdgcn_s_memrealtime();                        \
+            scan_state[G.total_waves + 16 + (uint64_t)s_ticket * 4u + (i)] = t_now - t_prev; \
+            t_prev = t_now;                                                                 \
+        }                                                                                   \
+    } while (0)
+#else
+#define ENC_STAMP(i) do { } while (0)
+#endif
+
 template <bool GEN, int WV = DRX_ENC_WAVES, uint32_t CAPW = kEncCapWords>
 __global__ __launch_bounds__(64 * WV, DRX_ENC_WAVES_PER_EU) void k_encode_fused(Geom G, const int16_t *__restrict__ in,
                                                       uint32_t *__restrict__ out, uint64_t out_cap,
@@ -346,6 +367,9 @@ __global__ __launch_bounds__(64 * WV, DRX_ENC_WAVES_PER_EU) void k_encode_fused(
     // wave.  One ticket per workgroup of kEncWaves waveforms: a single global counter serves
     // about 88 atomics per microsecond (a ticket per waveform made the whole kernel run at
     // exactly that rate: 1M waveforms in 11.9 ms).
+#ifdef DRX_ENC_STAMPS
+    uint64_t t_prev = __builtin_amdgcn_s_memrealtime();
+#endif
     if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1u);
     __syncthreads();
     const uint64_t g = (uint64_t)s_ticket * kEncWaves + (threadIdx.x >> 6);
@@ -467,6 +491,7 @@ __global__ __launch_bounds__(64 * WV, DRX_ENC_WAVES_PER_EU) void k_encode_fused(
     const int wv = threadIdx.x >> 6;
     if (lane == 0) s_mine[wv] = mine;
     __syncthreads();
+    ENC_STAMP(0);
     if (wv == 0) {
         uint64_t block_sum = 0;
 #pragma unroll
@@ -493,6 +518,7 @@ __global__ __launch_bounds__(64 * WV, DRX_ENC_WAVES_PER_EU) void k_encode_fused(
                 if (++spins > (1u << 22)) break;  // (the window loop below reports it)
             }
 #endif
+            ENC_STAMP(1);
             // kLbWin x 64 entries per poll.  The frontier of known prefixes advances one window per hop (a hop = an
             // agent-scope store becoming visible + an agent-scope load, 3-5 us under the encoder's own streaming loads), so
             // the window bounds the rate of the whole kernel: 128 entries carried ~25 workgroups per microsecond, just what
@@ -539,6 +565,7 @@ __global__ __launch_bounds__(64 * WV, DRX_ENC_WAVES_PER_EU) void k_encode_fused(
         }
         if (kAblate && (G.dbg & 1024u)) excl_blk = T * 2048ull * kEncWaves;  // ablation: look-back done, sparse placement all the same
         if (lane == 0) s_excl = excl_blk;
+        ENC_STAMP(2);
     }
     __syncthreads();
     uint64_t excl = s_excl;
@@ -575,6 +602,10 @@ __global__ __launch_bounds__(64 * WV, DRX_ENC_WAVES_PER_EU) void k_encode_fused(
             }
             if ((uint32_t)lane < n - n4) outp[n4 + (uint32_t)lane] = buf[n4 + (uint32_t)lane];
         }
+#ifdef DRX_ENC_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ENC_STAMP(3);
+#endif
         return;
     }
 
@@ -828,6 +859,17 @@ hipError_t launch_estimate_words(const Geom &G, const int16_t *d_in, unsigned lo
     return hipGetLastError();
 }
 
+// Ablation builds only: DRX_ENC_LDS_PAD = bytes of dynamic LDS added to every k_encode_fused launch (occupancy A/B at an
+// unchanged instruction stream).
+static unsigned enc_lds_pad() {
+#ifdef DRX_ABLATION
+    static const unsigned pad = [] { const char *e = getenv("DRX_ENC_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
+    return pad;
+#else
+    return 0u;
+#endif
+}
+
 // Single-pass encode (k_encode_fused).  d_scan: uint64[total_waves] + one uint32 ticket
 // word after it, zeroed here on the stream before every launch.
 hipError_t launch_encode_fused(const Geom &G, const int16_t *d_in, uint32_t *d_out, uint64_t out_cap,
@@ -844,7 +886,7 @@ hipError_t launch_encode_fused(const Geom &G, const int16_t *d_in, uint32_t *d_o
         constexpr bool GEN = decltype(gen_tag)::value;
         constexpr int WV = decltype(wv_tag)::value;
         constexpr uint32_t CAPW = decltype(cap_tag)::value;
-        k_encode_fused<GEN, WV, CAPW><<<blocks_for(G.total_waves, WV), 64 * WV, 0, s>>>(G, d_in, d_out, out_cap, d_chunk_word_off, d_wave_words,
+        k_encode_fused<GEN, WV, CAPW><<<blocks_for(G.total_waves, WV), 64 * WV, enc_lds_pad(), s>>>(G, d_in, d_out, out_cap, d_chunk_word_off, d_wave_words,
                                                                                     d_scan, ticket, d_status);
     };
     using std::integral_constant;
@@ -858,6 +900,20 @@ hipError_t launch_encode_fused(const Geom &G, const int16_t *d_in, uint32_t *d_o
         default: pick(integral_constant<int, kEncWaves>{}, integral_constant<uint32_t, kEncCapWords>{}); break;
     }
     mark(ev, 3, s);
+#ifdef DRX_ENC_STAMPS
+    if (G.total_waves >= 64) {
+        const uint64_t wgs = blocks_for(G.total_waves, kEncWaves);
+        unsigned long long *h = (unsigned long long *)malloc(wgs * 4 * sizeof(unsigned long long));
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, d_scan + G.total_waves + 16, wgs * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        double sum[4] = {0, 0, 0, 0};
+        for (uint64_t i = 0; i < wgs; ++i)
+            for (int j = 0; j < 4; ++j) sum[j] += (double)h[i * 4 + j];
+        free(h);
+        fprintf(stderr, "enc stamps (us per workgroup, 100 MHz ticks): encode %.2f  gate %.2f  window %.2f  copy-out %.2f  | %llu workgroups\n",
+                sum[0] / wgs / 100.0, sum[1] / wgs / 100.0, sum[2] / wgs / 100.0, sum[3] / wgs / 100.0, (unsigned long long)wgs);
+    }
+#endif
     return hipGetLastError();
 }
 

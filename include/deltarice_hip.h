@@ -166,7 +166,9 @@ drx_status drx_plan_last_timings(drx_plan *plan, float ms[4]);
 
 /* Tuning / diagnostics.  Returns DRX_ERR_ARG for unknown keys or values.
  *   "profile"      1: bracket the kernels with HIP events (drx_plan_last_timings)
- *   "encode_impl"  1 (default): single pass with look-back;  0: size pass + scan + pack pass
+ *   "encode_impl"  2 (default): single pass; one wavefront per waveform runs in the persistent form (wavefronts on their own,
+ *                  a scanner workgroup for the prefix sum) wherever the standard geometry applies;
+ *                  1: single pass with a look-back per workgroup everywhere (round 3's form);  0: size pass + scan + pack pass
  *   "decode_impl"  variant of the lane-per-waveform decode; each is bit-exact and covered by the parity tests:
  *        8 (default)  header walk inside the launch where the batch is large enough to hide it
  *        7            the same kernel behind a separate walk kernel
@@ -175,7 +177,8 @@ drx_status drx_plan_last_timings(drx_plan *plan, float ms[4]);
  *   "debug_flags"  dispatch overrides that force an alternative (still bit-exact) path, for tests and A/B timing:
  *        256 never the long-waveform paths, 512 long waveforms one workgroup each, 2048 never the parallel header walks,
  *        4096 never the pieces encoder, 8192 always the segment encoder, 32768 the pieces encoder also where one wavefront per
- *        waveform is the default, 65536 never the single-pass encoder's larger-buffer geometries (RiceParameter above 8).  (Ablation switches inside the kernels exist only in -DDRX_ABLATION builds.) */
+ *        waveform is the default, 65536 never the single-pass encoder's larger-buffer geometries (RiceParameter above 8),
+ *        262144 the persistent encoder on three workgroups (every wavefront codes many waveforms of a small batch).  (Ablation switches inside the kernels exist only in -DDRX_ABLATION builds.) */
 drx_status drx_ctx_set_option(drx_ctx *ctx, const char *key, int64_t value);
 
 #ifdef __cplusplus

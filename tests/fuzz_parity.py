@@ -104,13 +104,13 @@ def main():
             # wherever its geometry allows; 65536: the single-pass encoder's standard geometry only)
             for flags in (0, 256, 4096, 8192, 32768, 65536):
                 ctx.set_option("debug_flags", flags)
-                for eimpl in ((1, 0) if flags in (0, 256) else (1,)):
+                for eimpl in ((2, 1, 0) if flags in (0, 256) else (2,)):
                     ctx.set_option("encode_impl", eimpl)
                     log(f"  encode flags {flags} impl {eimpl}")
                     w, off = plan.encode(xd).to_numpy()
                     assert np.array_equal(off, ref_off), f"offsets (flags {flags}, encoder {eimpl})"
                     assert np.array_equal(w, ref_w), f"stream (flags {flags}, encoder {eimpl})"
-            ctx.set_option("encode_impl", 1)
+            ctx.set_option("encode_impl", 2)
             enc = dr.EncodedBatch(dev(ctx, ref_w.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), ref_w.size)
             lossless = taps is None or abs(taps[0]) == 1
             expect = x

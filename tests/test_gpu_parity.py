@@ -32,9 +32,9 @@ def dev(ctx, a):
 
 
 def gpu_encode(ctx, plan, x):
-    """Encodes with every encoder (the simple size/scan/pack passes; the single pass with look-back, forced
-    with debug flag 256; the pieces encoder wherever its geometry allows, flag 32768; and whatever the batch shape
-    selects by default), checks they agree, returns the default one's result."""
+    """Encodes with every encoder (the simple size/scan/pack passes; the single pass with a look-back per workgroup and
+    its persistent form, both forced with debug flag 256; the pieces encoder wherever its geometry allows, flag 32768; and
+    whatever the batch shape selects by default), checks they agree, returns the default one's result."""
     xd = dev(ctx, x.reshape(-1).view(np.int16))
     ctx.set_option("encode_impl", 0)
     enc0 = plan.encode(xd)
@@ -42,6 +42,9 @@ def gpu_encode(ctx, plan, x):
     ctx.set_option("encode_impl", 1)
     ctx.set_option("debug_flags", 256)
     w1, off1 = plan.encode(xd).to_numpy()
+    ctx.set_option("encode_impl", 2)
+    ws, offs = plan.encode(xd).to_numpy()
+    assert np.array_equal(offs, off0) and np.array_equal(ws, w0), "persistent single-pass encoder disagrees"
     ctx.set_option("debug_flags", 32768)
     w2, off2 = plan.encode(xd).to_numpy()
     ctx.set_option("debug_flags", 4096)
@@ -493,7 +496,7 @@ def test_general_prediction_filters_vs_oracle(ctx, O):
         opts = (8, 1000, len(taps)) + tuple(t & 0xFFFFFFFF for t in taps)
         ref_w, ref_off = O.encode_batch(x, 5000, opts)
         plan = ctx.plan_uniform(3, 5000, opts)
-        for eimpl in (0, 1):  # two-pass encoder; single-pass encoder (takes up to 4 taps)
+        for eimpl in (0, 1, 2):  # two-pass encoder; single-pass encoders (take up to 4 taps): per workgroup, persistent
             ctx.set_option("encode_impl", eimpl)
             enc = plan.encode(dev(ctx, x))
             w, off = enc.to_numpy()
@@ -531,6 +534,70 @@ def test_general_filters_through_the_pieces_encoder(ctx, O):
             assert np.array_equal(y, O.decode_batch(ref_w, ref_off, N, opts)), (taps, L, kind)
             if abs(taps[0]) == 1:
                 assert np.array_equal(y, x)
+
+
+def test_persistent_encoder_rings_and_streaming(ctx, O):
+    """k_encode_stream (encode_impl 2, round 4): wavefronts on their own, a ring of LDS per wavefront, a scanner workgroup.
+    With debug flag 262144 the launch has two coding workgroups, so every wavefront takes many waveforms around its ring:
+    code that wraps at the ring's end, waveforms that must wait for the one in front (short behind long), waveforms that
+    outgrow the ring (incompressible, or simply long: the streaming path), a shorter last waveform, a general filter, ragged
+    chunks, a capacity error -- all held to the oracle's bytes, and to the encoder of round 3."""
+    import deltarice_amd as dr
+    rng = np.random.default_rng(2024)
+    def noisy(n, sigma): return rng.normal(0, sigma, n).astype(np.int16)
+    def rough(n): return rng.integers(-32768, 32768, n, dtype=np.int16)
+    cases = []
+    cases.append(("headline-like", [7000 * 300] * 2, [7000] * 2, 3, None, noisy(7000 * 600, 10)))
+    x = noisy(7000 * 200, 10)
+    for w in (3, 17, 18, 90, 199):  # incompressible waveforms among compressible ones: 5469 words each, streamed
+        x[w * 7000:(w + 1) * 7000] = rough(7000)
+    cases.append(("streamed-among-ringed", [7000 * 200], [7000], 3, None, x))
+    cases.append(("all-streamed", [7000 * 40 + 123], [7000], 3, None, rough(7000 * 40 + 123)))
+    cases.append(("short", [100 * 3000 + 37], [100], 3, None, noisy(100 * 3000 + 37, 10)))
+    cases.append(("tiles-exact", [4096 * 150], [4096], 2, None, noisy(4096 * 150, 3)))
+    cases.append(("near-ring-size", [9000 * 120], [9000], 4, None, noisy(9000 * 120, 30)))   # ~8.5 bits per sample: ~2400 words
+    cases.append(("long", [30000 * 20, 30000 * 7 + 5], [30000, 30000], 3, None, noisy(30000 * 27 + 5, 10)))
+    cases.append(("fir4", [5000 * 100], [5000], 3, (1, -1, 1, -1), noisy(5000 * 100, 20)))
+    lens = [512, 2048, 7000, 16384, 0, 3333]
+    Ns = [512 * 40, 2048 * 9 + 17, 7000 * 30, 16384 * 4, 4321, 3333 * 21 + 1]
+    cases.append(("ragged", Ns, lens, 3, None, noisy(sum(Ns), 10)))
+    for name, Ns, Ls, k, taps, x in cases:
+        assert x.size == sum(Ns), name
+        uniform = len(set(Ns)) == 1 and len(set(Ls)) == 1
+        if uniform:
+            opts = (1 << k, Ls[0]) + ((len(taps),) + tuple(t & 0xFFFFFFFF for t in taps) if taps else ())
+            plan = ctx.plan_uniform(len(Ns), Ns[0], opts)
+        else:
+            plan = ctx.plan(Ns, Ls, 1 << k)
+        words, offs, at = [], [0], 0
+        for N, L in zip(Ns, Ls):
+            copts = ((1 << k, L) if L else (1 << k,)) + ((len(taps),) + tuple(t & 0xFFFFFFFF for t in taps) if taps else ())
+            w = O.encode_chunk(x[at:at + N], copts)
+            words.append(w)
+            offs.append(offs[-1] + w.size)
+            at += N
+        ref_w, ref_off = np.concatenate(words), np.array(offs, np.uint64)
+        xd = dev(ctx, x)
+        for flags in (256 | 4096, 256 | 4096 | 262144):
+            ctx.set_option("debug_flags", flags)
+            for eimpl in (2, 1):
+                ctx.set_option("encode_impl", eimpl)
+                enc = plan.encode(xd)
+                w, off = enc.to_numpy()
+                assert np.array_equal(off, ref_off), (name, flags, eimpl)
+                assert np.array_equal(w, ref_w), (name, flags, eimpl)
+        # too small an output buffer: reported, nothing written past it
+        ctx.set_option("encode_impl", 2)
+        cap = int(ref_w.size) - 5
+        out = torch.full((cap + 64,), 0x5A5A5A5A, dtype=torch.int32, device=ctx.device)
+        off_t = torch.empty(len(Ns) + 1, dtype=torch.int64, device=ctx.device)
+        plan.encode_async(xd, out[:cap], off_t)
+        with pytest.raises(dr.DeltaRiceError) as ei:
+            plan.finish()
+        assert ei.value.status == 3, name
+        assert bool((out[cap:] == 0x5A5A5A5A).all()), name
+        ctx.set_option("debug_flags", 0)
+    ctx.set_option("encode_impl", 2)
 
 
 def test_rice_parameter_optimiser_is_exact(ctx, O):
@@ -787,9 +854,13 @@ def test_decode_with_the_encoders_table_as_a_side_band(ctx, O):
         assert np.array_equal(y.cpu().numpy(), x), name
         assert np.array_equal(plan.decode(enc).cpu().numpy(), x)
         # a table that does not belong to the stream
-        for damage in ("plus1", "swap", "zero"):
+        for damage in ("plus1", "swap", "zero", "huge", "huge_mid"):
             t = table.clone()
-            if damage == "plus1":
+            if damage in ("huge", "huge_mid"):
+                # one oversized entry in front of valid ones (chunk 0; lane 0 or a lane in the middle of a wavefront): the
+                # 32-bit prefix sum of round 3 wrapped behind it and the lanes after it read up to 16 GB in front of the stream
+                t[0 if damage == "huge" else min(5, len(t) - 2)] = -16  # 0xFFFFFFF0
+            elif damage == "plus1":
                 t[len(t) // 2] += 1
             elif damage == "swap" and len(t) > 3 and int(t[0]) != int(t[1]):
                 t[0], t[1] = t[1].clone(), t[0].clone()

@@ -76,7 +76,10 @@ def check(lines, name):
         op, args = parts[0], parts[1:]
         # --- rule 2
         if pending is not None:
-            if op == "s_waitcnt" and "vmcnt(" in txt:
+            # only a wait for EVERYTHING outstanding proves the atomic has returned: `vmcnt(N)` with N > 0 may be a wait for
+            # loads issued before it.  (Labels and branches do not clear `pending`: the scan stays conservative across
+            # basic blocks, which is where the kernels' uses of the ticket sit.)
+            if op == "s_waitcnt" and re.search(r"vmcnt\(0\)", txt):
                 pending = None
             elif op in ("s_endpgm",):
                 pending = None

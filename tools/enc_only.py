@@ -15,6 +15,8 @@ import deltarice_amd as dr  # noqa: E402
 def main():
     ctx = dr.Context(0)
     ctx.set_option("profile", 1)
+    if os.environ.get("DRX_ENCODE_IMPL"):
+        ctx.set_option("encode_impl", int(os.environ["DRX_ENCODE_IMPL"]))
     n_chunks, W, L = 500, 2000, 7000
     g = torch.Generator(device=ctx.device).manual_seed(1234)
     x = (torch.randn(n_chunks * W * L, device=ctx.device, generator=g) * 10).to(torch.int16)

@@ -5,7 +5,7 @@
 # usage (GPU box): tools/r03_occupancy.sh      -> gpurun_out/r03_occ/table.txt
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r03_occ; mkdir -p $O; cd $R; : > $O/table.txt
 run() {  # lib pad flags label
-  DRX_LIB_PATH=$R/deltarice_amd/variants/lib_$1.so DRX_DEC_LDS_PAD=$2 timeout -k 10 150 python3 bench.py --cpu-seconds 0 --steps 6 --warmup 2 --debug-flags $3 2>/dev/null \
+  DRX_LIB_PATH=$R/deltarice_amd/variants/lib_$1.so DRX_DEC_LDS_PAD=$2 timeout -k 10 150 python3 bench.py --no-collect --cpu-seconds 0 --steps 6 --warmup 2 --debug-flags $3 2>/dev/null \
    | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print('%-44s dec %.3f ms  enc %.3f ms' % ('$4', d['kernel_ms']['decode_kernel'], d['kernel_ms']['encode_kernel']))" | tee -a $O/table.txt
 }
 for rep in 1 2; do

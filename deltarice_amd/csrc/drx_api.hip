@@ -292,8 +292,8 @@ static drx_status plan_alloc(drx_ctx *ctx, drx_plan *p) {  // (callers hold the 
     DRX_HIP(ctx, hipMalloc((void **)&p->d_wave_rel, W * sizeof(uint32_t)));
     DRX_HIP(ctx, hipMalloc((void **)&p->d_wave_off, W * sizeof(uint64_t)));
     DRX_HIP(ctx, hipMalloc((void **)&p->d_chunk_words, (p->G.n_chunks + 1) * sizeof(uint64_t)));
-    DRX_HIP(ctx, hipMalloc((void **)&p->d_scan, (2 * W + 18) * sizeof(uint64_t)));  // (k_encode_stream: size[W] | place[W] | control)
-    DRX_HIP(ctx, hipMemset(p->d_scan, 0, (2 * W + 18) * sizeof(uint64_t)));
+    DRX_HIP(ctx, hipMalloc((void **)&p->d_scan, (2 * W + 192) * sizeof(uint64_t)));  // (k_encode_stream: size[W] | place[W] | control)
+    DRX_HIP(ctx, hipMemset(p->d_scan, 0, (2 * W + 192) * sizeof(uint64_t)));
     DRX_HIP(ctx, hipMalloc((void **)&p->d_status, sizeof(DevStatus)));
     DRX_HIP(ctx, hipHostMalloc((void **)&p->h_status, sizeof(DevStatus), hipHostMallocDefault));
     memset(p->h_status, 0, sizeof(DevStatus));

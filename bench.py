@@ -349,9 +349,10 @@ def main():
     # passes (collect_traffic(), before the GPU was touched) -- or, where rocprofv3 is missing or a pass failed, read from the
     # newest committed passes of the same command, flagged stale when the kernel sources have changed since
     traffic = traffic_enc = traffic_source = None
+    enc_kernel = "k_encode_stream"  # (encode_impl 2, the default since round 4; encode_impl 1 = k_encode_fused)
     if traffic_kernels is not None:
         traffic = traffic_kernels.get("k_decode_lanes", {}).get("hbm_bytes")
-        traffic_enc = traffic_kernels.get("k_encode_fused", {}).get("hbm_bytes")
+        traffic_enc = (traffic_kernels.get(enc_kernel) or traffic_kernels.get("k_encode_fused", {})).get("hbm_bytes")
         traffic_source = traffic_note
     else:
         tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
@@ -361,7 +362,7 @@ def main():
             stale = tj.get("kernel_sources_sha16") != _traffic_tools().kernel_sources_sha()
             if not stale:
                 traffic = tj["kernels"].get("k_decode_lanes", {}).get("hbm_bytes")
-                traffic_enc = tj["kernels"].get("k_encode_fused", {}).get("hbm_bytes")
+                traffic_enc = (tj["kernels"].get(enc_kernel) or tj["kernels"].get("k_encode_fused", {})).get("hbm_bytes")
             traffic_source = (f"profiles/{os.path.basename(tfiles[-1])} (commit {tj.get('git_head')}): rocprofv3 --pmc passes of this "
                               "command on an earlier run, NOT collected by this run"
                               + ("; dropped: the kernel sources have changed since" if stale else "")
@@ -397,7 +398,7 @@ def main():
             "backend": (a.backend if world > 1 else None),
             "encode_GBps": raw_bytes / (enc_ms[3] * 1e-3) / 1e9,
             "decode_GBps": raw_bytes / (dec_ms[3] * 1e-3) / 1e9,
-            # HIP events on the codec's stream.  encode: [state memset | - | k_encode_fused];
+            # HIP events on the codec's stream.  encode: [state memset | - | k_encode_stream];
             # decode: [granule memset | k_decode_lanes (header-chain walk fused in)]
             "kernel_ms": {"encode_prepare": float(enc_ms[0] + enc_ms[1]), "encode_kernel": float(enc_ms[2]),
                           "decode_prepare": float(dec_ms[0]), "decode_kernel": float(dec_ms[1])},
@@ -407,7 +408,7 @@ def main():
                          # pass --no-collect; profiles/r04_notes.md has both forms measured on one box)
                          "traffic_collected_in_run": traffic_kernels is not None,
                          "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": dec_kernel_ms},
-            "roofline_encode": {"bound": "hbm", "kernel": "k_encode_fused", "achieved": algo_bytes / (pack_ms * 1e-3) / 1e9,
+            "roofline_encode": {"bound": "hbm", "kernel": enc_kernel, "achieved": algo_bytes / (pack_ms * 1e-3) / 1e9,
                                 "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                 "frac": algo_bytes / (pack_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic_enc, "traffic_source": traffic_source,
                                 "kernel_ms": pack_ms},

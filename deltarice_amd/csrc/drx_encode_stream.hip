@@ -38,9 +38,10 @@
 
 namespace drx {
 
-// wavefronts per workgroup = waveforms per ticket; 16 wavefronts per CU either way
+// wavefronts per workgroup = waveforms per ticket; 16 wavefronts per CU either way (4: 4.95 ms on the headline, 8: 5.1 -- the
+// rendezvous of four costs less than that of eight; with the priority feedback below 4.80 / 4.84)
 #ifndef DRX_ES_WAVES
-#define DRX_ES_WAVES 8
+#define DRX_ES_WAVES 4
 #endif
 constexpr int kEsWaves = DRX_ES_WAVES;
 constexpr uint32_t kEsFront = 4;   // pad words in front of a ring (place_words writes up to four words below a lane's last)
@@ -53,6 +54,9 @@ constexpr uint32_t kEsCtrlWords = 32;  // uint64 words of control state: 128 byt
 #define DRX_ES_RING 2496
 #endif
 constexpr uint32_t kEsRing = DRX_ES_RING;
+#ifndef DRX_ES_PRIO
+#define DRX_ES_PRIO 1
+#endif
 #ifndef DRX_ES_POLL_SLEEP
 #define DRX_ES_POLL_SLEEP 4
 #endif
@@ -105,28 +109,34 @@ __device__ __forceinline__ void es_scanner(uint64_t total, uint32_t wv_per_ticke
     unsigned long long sc_rounds = 0, sc_idle = 0, sc_full = 0;
     const uint64_t sc_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    auto sample = [&](uint64_t (&v)[kScPer], uint64_t at) {
+#pragma unroll
+        for (int j = 0; j < (int)kScPer; ++j) {
+            const uint64_t e = at + 64u * j + (uint32_t)lane;
+            v[j] = e < total ? es_load(size + e) : kEsFlag;  // (beyond the batch: an empty entry; the run is cut at `total`)
+        }
+    };
     while (pos < total) {
 #ifdef DRX_ENC_STAMPS
         ++sc_rounds;
 #endif
         uint64_t v[kScPer];
-#pragma unroll
-        for (int j = 0; j < (int)kScPer; ++j) {
-            const uint64_t e = pos + 64u * j + (uint32_t)lane;
-            v[j] = e < total ? es_load(size + e) : kEsFlag;  // (beyond the batch: an empty entry; the run is cut at `total`)
-        }
-        uint64_t r = 0;  // entries from the frontier on that have all been published
+        const uint64_t bs = pos;
+        sample(v, pos);
+        uint64_t run = 0;  // entries from bs on that have their place or have been published
         bool open = true, big = false;
 #pragma unroll
         for (int j = 0; j < (int)kScPer; ++j) {
-            const uint64_t m = __ballot((v[j] >> 63) != 0);
+            const uint64_t e = bs + 64u * j + (uint32_t)lane;
+            const uint64_t m = __ballot(e < pos || (v[j] >> 63) != 0);
             const uint32_t l = (m == ~0ull) ? 64u : (uint32_t)__builtin_ctzll(~m);
-            r += open ? l : 0u;
+            run += open ? l : 0u;
             open = open && l == 64u;
             big = big || __any((v[j] & ~kEsFlag) >= (1ull << 24));
         }
-        r = r < total - pos ? r : total - pos;
-        if (r == 0) {
+        uint64_t end = bs + run;  // the new frontier
+        end = end < total ? end : total;
+        if (end <= pos) {
 #ifdef DRX_ENC_STAMPS
             ++sc_idle;
 #endif
@@ -139,14 +149,14 @@ __device__ __forceinline__ void es_scanner(uint64_t total, uint32_t wv_per_ticke
         }
         idle = 0;
 #ifdef DRX_ENC_STAMPS
-        if (r == 64u * kScPer) ++sc_full;
+        if (end - bs == 64u * kScPer) ++sc_full;
 #endif
         uint64_t running = 0;
 #pragma unroll
         for (int j = 0; j < (int)kScPer; ++j) {
-            if (64u * j < r) {  // (wave uniform)
-                const uint64_t rel = 64u * j + (uint32_t)lane;
-                const bool in = rel < r;
+            if (bs + 64u * j < end) {  // (wave uniform)
+                const uint64_t e = bs + 64u * j + (uint32_t)lane;
+                const bool in = e >= pos && e < end;
                 const uint64_t val = in ? (v[j] & ~kEsFlag) : 0ull;
                 uint64_t inc;
                 if (!big) {
@@ -159,15 +169,15 @@ __device__ __forceinline__ void es_scanner(uint64_t total, uint32_t wv_per_ticke
                         if (lane >= d) inc += t;
                     }
                 }
-                if (in) es_store(place + pos + rel, kEsFlag | (base + running + inc - val));
+                if (in) es_store(place + e, kEsFlag | (base + running + inc - val));
 #ifdef DRX_ENC_STAMPS
-                if (in && trace) trace[5ull * (pos + rel) * wv_per_ticket + 4] = __builtin_amdgcn_s_memrealtime();
+                if (in && trace) trace[5ull * e * wv_per_ticket + 4] = __builtin_amdgcn_s_memrealtime();
 #endif
                 running += big ? __shfl(inc, 63) : (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)inc, 63);
             }
         }
         base += running;
-        pos += r;
+        pos = end;
     }
 #ifdef DRX_ENC_STAMPS
     if (lane == 0) {
@@ -187,7 +197,7 @@ __global__ __launch_bounds__(64 * WV, 4) void k_encode_stream(Geom G, const int1
                                                               uint64_t *__restrict__ place, uint32_t *__restrict__ ctrl,
                                                               DevStatus *st, unsigned long long *prof) {
     __shared__ __attribute__((aligned(16))) uint32_t ring_all[WV][kEsFront + RING + kEsBack];
-    __shared__ uint32_t s_role, s_arrive, s_ticket[2];
+    __shared__ uint32_t s_role, s_arrive, s_ticket[4];
     __shared__ uint64_t s_mine[2][WV];              // sizes of the waveforms of the last two tickets
     __shared__ uint64_t s_place_v[2];               // place of a ticket, once one wavefront has seen it ...
     __shared__ uint32_t s_place_t[2];               // ... and which ticket (+ 1) that was
@@ -401,11 +411,11 @@ __global__ __launch_bounds__(64 * WV, 4) void k_encode_stream(Geom G, const int1
         if (lane == 0) arr = __hip_atomic_fetch_add((lds_u32 *)&s_arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         arr = (uint32_t)__builtin_amdgcn_readfirstlane((int)arr);
         if (arr == (uint32_t)WV * cyc) {
-            if (lane == 0) s_ticket[cyc & 1u] = atomicAdd(ctrl + 32, 1u);
+            if (lane == 0) s_ticket[cyc & 3u] = atomicAdd(ctrl + 32, 1u);
         }
         __syncthreads();
         ES_COUNT(6, __builtin_amdgcn_s_memrealtime() - es_tr);
-        const uint32_t T = s_ticket[cyc & 1u];
+        const uint32_t T = s_ticket[cyc & 3u];
         // the ticket before: its total to the scanner, and where in it this wavefront's waveform lies
         if (cyc) {
             uint64_t sum = 0, before = 0;
@@ -478,6 +488,14 @@ __global__ __launch_bounds__(64 * WV, 4) void k_encode_stream(Geom G, const int1
                 const bool must = fits && ((P + tile_bits + 31u) >> 5) >= (uint64_t)limit;
                 if (seen || must) {
                     if (seen) ES_COUNT(2, 1);
+#if DRX_ES_PRIO
+                    // A wavefront that has to wait for its place is AHEAD of the stream's frontier; one that finds the place of
+                    // its last waveform almost as soon as it looks is what the others are waiting for.  Issue priority on
+                    // the SIMD follows (4.96-5.02 -> 4.79-4.83 ms on the headline; more levels or other thresholds: the same).
+                    if (!seen) __builtin_amdgcn_s_setprio(0);
+                    else if (P < (uint64_t)(4u * kTile * 7u)) __builtin_amdgcn_s_setprio(2);
+                    else __builtin_amdgcn_s_setprio(1);
+#endif
                     copy_out(seen ? ex : wait_place());
                     limit = gap();
                 }

@@ -52,7 +52,7 @@ $(PLUGIN): $(CSRC)/h5z_deltarice.c include/deltarice_h5filter.h include/deltaric
 h5io: $(H5IO)
 $(H5IO): $(CSRC)/h5_direct.c include/deltarice_h5io.h include/deltarice_hip.h $(HIP_LIB)
 	$(CC) -O2 -std=gnu11 -Wall -fPIC -shared -Iinclude -I$(HDF5_DIR)/include -I/opt/rocm/include $< -o $@ \
-	    -Ldeltarice_amd -ldeltarice_hip -L$(HDF5_DIR)/lib -lhdf5 -L/opt/rocm/lib -lamdhip64 -ldl \
+	    -Ldeltarice_amd -ldeltarice_hip -L$(HDF5_DIR)/lib -lhdf5 -L/opt/rocm/lib -lamdhip64 -ldl -lpthread \
 	    -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(HDF5_DIR)/lib -Wl,-rpath,/opt/rocm/lib
 
 # deltaRice/h5.pyx -> deltaRice/h5.cpython-*.so, linked against the plugin library (whose callback runs the HIP codec).

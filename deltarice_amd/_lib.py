@@ -40,6 +40,7 @@ SIGNATURES = {
     "drx_ctx_last_error": (C.c_char_p, [_vp]),
     "drx_ctx_stream": (_vp, [_vp]),
     "drx_ctx_device": (C.c_int, [_vp]),
+    "drx_ctx_host_staging": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "drx_ctx_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
     "drx_plan_create": (C.c_int, [_vp, _u64, C.POINTER(_u32), C.POINTER(_u32), _u32, C.POINTER(_vp)]),
     "drx_plan_create_uniform": (C.c_int, [_vp, _u64, _u32, _u32, _u32, C.POINTER(_vp)]),

@@ -66,6 +66,12 @@ class Context:
         if st != _lib.DRX_OK:
             raise DeltaRiceError(st, "drx_ctx_create")
         self._h = h
+        # A/B timing from the environment (tools/): DRX_ENCODE_IMPL / DRX_DECODE_IMPL = the context options of the same name
+        import os
+        for key in ("encode_impl", "decode_impl"):
+            v = os.environ.get("DRX_" + key.upper())
+            if v:
+                self.set_option(key, int(v))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -39,6 +39,7 @@ struct drx_ctx {
     void *d_enc = nullptr;   size_t enc_cap = 0;
     uint64_t *d_off = nullptr;
     void *h_pin = nullptr;   size_t pin_cap = 0;
+    void *h_stage = nullptr; size_t stage_cap = 0;  // drx_ctx_host_staging(): the direct-chunk HDF5 path's staging buffer
     // the host path's plan is kept between calls: HDF5 calls the filter once per chunk with the same
     // geometry, and creating a plan costs eight hipMalloc/hipFree pairs (about a millisecond)
     drx_plan *host_plan = nullptr;
@@ -78,6 +79,7 @@ struct drx_plan {
     uint64_t *d_wave_off = nullptr;    // decode: absolute header position
     uint64_t *d_chunk_words = nullptr;
     uint64_t *d_scan = nullptr;        // look-back state of the single-pass encoder + ticket
+    uint64_t enc_words_per_wave = 0;   // of the plan's last encode (0: none yet)
     int32_t *d_taps = nullptr;         // general prediction filter (nullptr: delta)
     uint32_t *d_seg_bits = nullptr;    // few long waveforms: bits and bit position of every 8192-sample segment,
     uint64_t *d_seg_pos = nullptr;     // allocated by the first encode that needs them
@@ -212,6 +214,7 @@ void drx_ctx_destroy(drx_ctx *c) {
     if (c->d_enc) (void)hipFree(c->d_enc);
     if (c->d_off) (void)hipFree(c->d_off);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     if (c->side.s) (void)hipStreamDestroy(c->side.s);
     if (c->side.fork) (void)hipEventDestroy(c->side.fork);
@@ -228,6 +231,19 @@ drx_status drx_ctx_synchronize(drx_ctx *c) {
 
 const char *drx_ctx_last_error(const drx_ctx *c) { return c ? c->last_error.c_str() : ""; }
 void *drx_ctx_stream(const drx_ctx *c) { return c ? (void *)c->stream : nullptr; }
+drx_status drx_ctx_host_staging(drx_ctx *ctx, size_t bytes, void **host_out) {
+    if (!ctx || !host_out) return DRX_ERR_ARG;
+    DRX_ON_DEVICE(ctx);
+    if (ctx->stage_cap < bytes) {
+        if (ctx->h_stage) { (void)hipStreamSynchronize(ctx->stream); (void)hipHostFree(ctx->h_stage); ctx->h_stage = nullptr; ctx->stage_cap = 0; }
+        const size_t want = bytes + bytes / 8 + 4096;
+        const hipError_t e = hipHostMalloc(&ctx->h_stage, want, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(ctx, DRX_ERR_NOMEM, "pinned staging buffer of %zu bytes: %s", want, hipGetErrorString(e));
+        ctx->stage_cap = want;
+    }
+    *host_out = ctx->h_stage;
+    return DRX_OK;
+}
 int drx_ctx_device(const drx_ctx *c) { return c ? c->device : -1; }
 
 drx_status drx_ctx_set_option(drx_ctx *c, const char *key, int64_t value) {
@@ -581,6 +597,21 @@ drx_status drx_plan_read_wave_words(drx_plan *p, uint32_t *host_out) {
     return DRX_OK;
 }
 
+// k_encode_stream or k_encode_fused?  The persistent form wins where a wavefront's ring (kEsRingWords) holds a waveform's
+// code AND most of the next one's (the next is coded while the first waits for its place), and where the batch feeds its
+// 4096 wavefronts a few waveforms each -- measured (profiles/r04_notes.md section 1e), stream / fused: 100 chunks of 14 M
+// samples at WaveformLength 3600 ... 8192 (1060-1660 words per waveform) 1.02-1.70 / 1.09-1.97 ms, at 10000 (2020 words: the
+// next waveform cannot start) 1.72 / 1.25; AR(1) under m = 4 (1740 words, 11 % escapes) 6.44 / 5.70; one chunk of 2000
+// waveforms 0.031 / 0.023, ten chunks 0.126 / 0.137.  A waveform's words are not known before it is coded: the plan's last
+// encode says (the same data shape comes again), and before that k + 3.5 bits per sample (the RiceParameter that suits).
+static bool stream_encoder_suits(const drx_plan *p) {
+    const Geom &G = p->G;
+    if (fused_wide(G) != 0 || G.total_waves < 8192u) return false;
+    const uint64_t L = G.uniform ? G.u_wave_len : G.max_wave_len64 / 64u;
+    const uint64_t words = p->enc_words_per_wave ? p->enc_words_per_wave : (L * (2u * G.k + 7u)) / 64u;
+    return words <= (uint64_t)kEsRingWords * 67u / 100u;
+}
+
 drx_status drx_encode(drx_plan *p, const int16_t *d_in, uint32_t *d_out, uint64_t out_cap_words,
                       uint64_t *d_chunk_word_off) {
     if (!p || !d_in || !d_out || !d_chunk_word_off) return DRX_ERR_ARG;
@@ -601,7 +632,7 @@ drx_status drx_encode(drx_plan *p, const int16_t *d_in, uint32_t *d_out, uint64_
         DRX_HIP(ctx, launch_encode_long(p->G, d_in, d_out, out_cap_words, d_chunk_word_off, p->d_wave_words, p->d_wave_rel,
                                         p->d_chunk_words, p->d_seg_bits, p->d_seg_pos, p->d_status,
                                         ctx->profile ? p->ev : nullptr, ctx->stream));
-    } else if (ctx->encode_impl == 2 && (p->G.n_taps == 0 || p->G.enc_fast) && fused_wide(p->G) == 0)
+    } else if (ctx->encode_impl == 2 && (p->G.n_taps == 0 || p->G.enc_fast) && (stream_encoder_suits(p) || (ctx->debug_flags & 524288u)))
         DRX_HIP(ctx, launch_encode_stream(p->G, d_in, d_out, out_cap_words, d_chunk_word_off, p->d_wave_words,
                                           p->d_scan, p->d_status, ctx->profile ? p->ev : nullptr, ctx->stream));
     else if (single && (p->G.n_taps == 0 || p->G.enc_fast))
@@ -702,6 +733,8 @@ drx_status drx_plan_finish(drx_plan *p, uint64_t *total_words) {
     DRX_HIP(ctx, hipMemcpyAsync(p->h_status, p->d_status, sizeof(DevStatus), hipMemcpyDeviceToHost, ctx->stream));
     DRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (total_words) *total_words = p->h_status->total_words;
+    // what an encode measured decides the next encode's kernel (stream_encoder_suits())
+    if (p->last_was_encode && !p->h_status->err && p->G.total_waves) p->enc_words_per_wave = p->h_status->total_words / p->G.total_waves;
     if (p->h_status->err & kErrInternal) return fail(ctx, DRX_ERR_DEVICE, "encoder look-back timed out (internal error)");
     if (p->h_status->err & kErrCorrupt) return fail(ctx, DRX_ERR_CORRUPT, "encoded input failed header-chain validation");
     if (p->h_status->err & kErrCapacity)

@@ -50,10 +50,7 @@ constexpr uint64_t kEsFlag = 1ull << 63;
 constexpr uint32_t kEsCtrlWords = 32;  // uint64 words of control state: 128 bytes each for the role and the ticket counter
 // ring words per wavefront: 16 x (2496 + 16) x 4 bytes = 157 KB, 16 wavefronts per CU (the geometry fused_wide() = 1 already
 // runs); a 1414-word waveform (the headline's) leaves the next one 1072 words = nine tiles before it has to know its place
-#ifndef DRX_ES_RING
-#define DRX_ES_RING 2496
-#endif
-constexpr uint32_t kEsRing = DRX_ES_RING;
+constexpr uint32_t kEsRing = kEsRingWords;  // (drx_internal.h: the dispatch needs it too)
 #ifndef DRX_ES_PRIO
 #define DRX_ES_PRIO 1
 #endif

@@ -45,6 +45,7 @@ struct Geom {
                    //  4096 never the pieces encoder   32768 the pieces encoder wherever its geometry allows
                    //  131072 ragged batches: one decode launch behind both header walks instead of one behind each
                    //  262144 k_encode_stream on three workgroups (tests: every wavefront goes around its ring)
+                   //  524288 k_encode_stream (encode_impl 2) whatever the batch (else: where stream_encoder_suits())
                    // Ablation switches INSIDE the kernels, compiled only with -DDRX_ABLATION (results invalid):
                    //   decode:   1 skip the output stores   2 skip the stream loads
                    //             4 request pieces without counting on the round's minimum consumption   16384 long: no stores
@@ -122,8 +123,12 @@ hipError_t launch_encode_fused(const Geom &G, const int16_t *d_in, uint32_t *d_o
                                uint64_t *d_chunk_word_off, uint32_t *d_wave_words, uint64_t *d_scan,
                                DevStatus *d_status, hipEvent_t *ev, hipStream_t s);
 
-// the persistent form of the single pass (drx_encode_stream.hip): wavefronts on their own, a ring per wavefront, a scanner
-// workgroup.  d_scan: uint64[2 * total_waves + 10]
+// the persistent form of the single pass (drx_encode_stream.hip): a ring of kEsRingWords LDS words per wavefront, a scanner
+// wavefront.  d_scan: uint64[2 * total_waves + 48]
+#ifndef DRX_ES_RING
+#define DRX_ES_RING 2496
+#endif
+constexpr uint32_t kEsRingWords = DRX_ES_RING;
 hipError_t launch_encode_stream(const Geom &G, const int16_t *d_in, uint32_t *d_out, uint64_t out_cap,
                                 uint64_t *d_chunk_word_off, uint32_t *d_wave_words, uint64_t *d_scan,
                                 DevStatus *d_status, hipEvent_t *ev, hipStream_t s);

@@ -80,6 +80,11 @@ drx_status drx_ctx_synchronize(drx_ctx *ctx);
 const char *drx_ctx_last_error(const drx_ctx *ctx);
 void *drx_ctx_stream(const drx_ctx *ctx);
 int drx_ctx_device(const drx_ctx *ctx); /* the HIP device the context was created on (-1 for NULL) */
+/* A pinned host buffer of at least `bytes` that belongs to the context and is kept across calls (grown when a call asks for
+ * more; freed with the context): staging for callers that move batches between host memory and the device, such as the
+ * direct-chunk HDF5 path -- a fresh hipHostMalloc per call costs more than the copy it serves (7 ms for 113 MB).
+ * One user at a time, like the context itself. */
+drx_status drx_ctx_host_staging(drx_ctx *ctx, size_t bytes, void **host_out);
 
 /* Plans.  chunk_wave_len[c] == 0 means "whole chunk" (WaveformLength = -1).
  * Allocates the per-waveform tables and every scratch buffer the batch's geometry can need on the device;
@@ -178,7 +183,8 @@ drx_status drx_plan_last_timings(drx_plan *plan, float ms[4]);
  *        256 never the long-waveform paths, 512 long waveforms one workgroup each, 2048 never the parallel header walks,
  *        4096 never the pieces encoder, 8192 always the segment encoder, 32768 the pieces encoder also where one wavefront per
  *        waveform is the default, 65536 never the single-pass encoder's larger-buffer geometries (RiceParameter above 8),
- *        262144 the persistent encoder on three workgroups (every wavefront codes many waveforms of a small batch).  (Ablation switches inside the kernels exist only in -DDRX_ABLATION builds.) */
+ *        262144 the persistent encoder on three workgroups (every wavefront codes many waveforms of a small batch),
+ *        524288 the persistent encoder (encode_impl 2) whatever the batch's size and expected code length.  (Ablation switches inside the kernels exist only in -DDRX_ABLATION builds.) */
 drx_status drx_ctx_set_option(drx_ctx *ctx, const char *key, int64_t value);
 
 #ifdef __cplusplus

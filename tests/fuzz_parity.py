@@ -103,9 +103,10 @@ def main():
             # (256: no long-waveform paths; 4096: no pieces encoder; 8192: the segment encoder; 32768: the pieces encoder
             # wherever its geometry allows; 65536: the single-pass encoder's standard geometry only)
             for flags in (0, 256, 4096, 8192, 32768, 65536):
-                ctx.set_option("debug_flags", flags)
                 for eimpl in ((2, 1, 0) if flags in (0, 256) else (2,)):
                     ctx.set_option("encode_impl", eimpl)
+                    # (524288: the persistent encoder whatever the batch's size, where the flags leave the choice to it)
+                    ctx.set_option("debug_flags", flags | (524288 if eimpl == 2 and flags in (0, 256) else 0))
                     log(f"  encode flags {flags} impl {eimpl}")
                     w, off = plan.encode(xd).to_numpy()
                     assert np.array_equal(off, ref_off), f"offsets (flags {flags}, encoder {eimpl})"

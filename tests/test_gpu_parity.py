@@ -43,6 +43,7 @@ def gpu_encode(ctx, plan, x):
     ctx.set_option("debug_flags", 256)
     w1, off1 = plan.encode(xd).to_numpy()
     ctx.set_option("encode_impl", 2)
+    ctx.set_option("debug_flags", 256 | 524288)  # (524288: the persistent form whatever the batch's size)
     ws, offs = plan.encode(xd).to_numpy()
     assert np.array_equal(offs, off0) and np.array_equal(ws, w0), "persistent single-pass encoder disagrees"
     ctx.set_option("debug_flags", 32768)
@@ -498,9 +499,11 @@ def test_general_prediction_filters_vs_oracle(ctx, O):
         plan = ctx.plan_uniform(3, 5000, opts)
         for eimpl in (0, 1, 2):  # two-pass encoder; single-pass encoders (take up to 4 taps): per workgroup, persistent
             ctx.set_option("encode_impl", eimpl)
+            ctx.set_option("debug_flags", 524288 if eimpl == 2 else 0)
             enc = plan.encode(dev(ctx, x))
             w, off = enc.to_numpy()
             assert np.array_equal(off, ref_off) and np.array_equal(w, ref_w), (taps, eimpl)
+        ctx.set_option("debug_flags", 0)
         ref_y = O.decode_batch(ref_w, ref_off, 5000, opts)
         for impl in (0, 7, 8):  # simple kernel; staged kernel (taken when taps[0] = +-1 and <= 4 taps), walk separate / fused
             ctx.set_option("decode_impl", impl)
@@ -578,7 +581,7 @@ def test_persistent_encoder_rings_and_streaming(ctx, O):
             at += N
         ref_w, ref_off = np.concatenate(words), np.array(offs, np.uint64)
         xd = dev(ctx, x)
-        for flags in (256 | 4096, 256 | 4096 | 262144):
+        for flags in (256 | 4096 | 524288, 256 | 4096 | 524288 | 262144):
             ctx.set_option("debug_flags", flags)
             for eimpl in (2, 1):
                 ctx.set_option("encode_impl", eimpl)

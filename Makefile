@@ -14,7 +14,7 @@ HIP_LIB   := deltarice_amd/libdeltarice_hip.so
 PLUGIN    := deltarice_amd/plugin/libh5deltarice.so
 HIP_SRCS  := $(CSRC)/drx_encode_kernels.hip $(CSRC)/drx_encode_stream.hip $(CSRC)/drx_decode_kernels.hip $(CSRC)/drx_blocks.hip $(CSRC)/drx_pieces.hip $(CSRC)/drx_iir.hip $(CSRC)/drx_api.hip
 HIP_OBJS  := $(HIP_SRCS:.hip=.o)
-HIP_HDRS  := $(CSRC)/drx_internal.h $(CSRC)/drx_device.h $(CSRC)/drx_encode.h $(CSRC)/drx_walk.h include/deltarice_hip.h
+HIP_HDRS  := $(CSRC)/drx_internal.h $(CSRC)/drx_device.h $(CSRC)/drx_encode.h $(CSRC)/drx_walk.h $(CSRC)/drx_iir_math.h include/deltarice_hip.h
 
 H5IO      := deltarice_amd/libdeltarice_h5io.so
 

@@ -552,6 +552,7 @@ drx_status drx_plan_set_filter(drx_plan *p, uint32_t n_taps, const int32_t *taps
         p->G.n_taps = 0;
         p->G.taps = nullptr;
         p->G.iir_tab = nullptr;
+        p->G.blk_iir_tab = nullptr;
         return DRX_OK;
     }
     if (n_taps <= 4) {
@@ -564,12 +565,16 @@ drx_status drx_plan_set_filter(drx_plan *p, uint32_t n_taps, const int32_t *taps
         for (uint32_t j = 1; j < 4; ++j) p->G.fast_nt[j - 1] = (j < n_taps) ? 0u - (uint32_t)taps[j] : 0u;
     }
     p->G.iir_tab = nullptr;
+    p->G.blk_iir_tab = nullptr;
     if (p->G.fast_taps && p->d_iir_state) {  // the block decoder's geometry: the inverse filter's matrix tables
-        std::vector<uint32_t> tab(kIirTabWords);
+        const uint32_t words = kIirTabWords + blocks_iir_tab_words();  // k_iir_tiles' tables, then the block decoder's own
+        std::vector<uint32_t> tab(words);
         iir_tables(p->G.fast_nt, p->G.fast_t0neg, tab.data());
-        if (!p->d_iir_tab) DRX_HIP(ctx, hipMalloc((void **)&p->d_iir_tab, kIirTabWords * sizeof(uint32_t)));
-        DRX_HIP(ctx, hipMemcpy(p->d_iir_tab, tab.data(), kIirTabWords * sizeof(uint32_t), hipMemcpyHostToDevice));
+        blocks_iir_tables(p->G.fast_nt, p->G.fast_t0neg, tab.data() + kIirTabWords);
+        if (!p->d_iir_tab) DRX_HIP(ctx, hipMalloc((void **)&p->d_iir_tab, words * sizeof(uint32_t)));
+        DRX_HIP(ctx, hipMemcpy(p->d_iir_tab, tab.data(), words * sizeof(uint32_t), hipMemcpyHostToDevice));
         p->G.iir_tab = p->d_iir_tab;
+        p->G.blk_iir_tab = p->d_iir_tab + kIirTabWords;
     }
     if (!p->d_taps) DRX_HIP(ctx, hipMalloc((void **)&p->d_taps, DRX_MAX_TAPS * sizeof(int32_t)));
     DRX_HIP(ctx, hipMemcpy(p->d_taps, taps, n_taps * sizeof(int32_t), hipMemcpyHostToDevice));

@@ -41,6 +41,7 @@
 
 #include "drx_device.h"
 #include "drx_internal.h"
+#include "drx_iir_math.h"
 
 namespace drx {
 
@@ -284,7 +285,17 @@ __device__ __forceinline__ void blk_skip_pairs(const uint32_t *W, uint32_t k, bo
     if (enable && !(Qa_l > qlim)) Qp = Qa_l;  // (no pair taken: Qa_l is Qp)
 }
 
-template <int NT, bool RESID, int SW>
+// FUSE (with RESID): the inverse of a general prediction filter (at most four taps, taps[0] = +-1; src/deltaRice.c:91-102) runs
+// INSIDE this kernel, over a block's residuals while they sit in LDS in output order: samples, not residuals, are what reaches
+// HBM, and no second pass (k_iir_tiles: 2 + 2 more bytes of traffic per sample) follows.  The recurrence is linear over
+// Z / 2^16 (drx_iir.hip has the algebra): lane t owns samples [t M, (t + 1) M) of the staging buffer (M = its lane share, so
+// equal run lengths and matrices from a table), pass 1 = zero-state response of every run (lane 0 starts from the state in
+// front of the block instead), a scan over the lanes with A^(M 2^d), pass 2 = the runs again from their true states.  The state
+// behind a block is its last three samples: it stays with thread 0 through a run of blocks, and goes from a run's last block
+// to the next run's first through `xstate` (one 8-byte word per block slot, its own flag).  That hand-over is a serial chain
+// along a waveform, so the host fuses only where runs of ONE waveform are rarely in flight together (as many waveforms as
+// resident workgroups); elsewhere the two-pass form stays.
+template <int NT, bool RESID, int SW, bool FUSE = false>
 __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
                                                       const uint64_t *__restrict__ wave_off,
                                                       const uint32_t *__restrict__ wave_words,
@@ -293,7 +304,9 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
                                                       uint32_t *__restrict__ ends, uint32_t *__restrict__ ticket,
                                                       uint32_t *__restrict__ fail, uint32_t *__restrict__ suspect,
                                                       DevStatus *st, int16_t *__restrict__ out, unsigned long long *prof,
-                                                      const uint32_t *__restrict__ wave_list, uint32_t n_list) {
+                                                      const uint32_t *__restrict__ wave_list, uint32_t n_list,
+                                                      const uint32_t *__restrict__ itab, uint64_t *__restrict__ xstate) {
+    static_assert(!FUSE || RESID, "the fused inverse filter works on residuals");
     using BG = BlkGeom<NT, SW>;
     constexpr int kBlkSegW = SW;
     constexpr uint32_t kBlkLaneCap = BG::kLaneCap, kBlkLaneStride = BG::kLaneStride, kCap2 = BG::kLaneCap / 2u;
@@ -303,7 +316,7 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
     constexpr uint32_t kSegBits = 32u * kBlkSegW;
     // one LDS object, the image first: its three-word windows are read with immediate offsets from address 0
     constexpr uint32_t kWSize = BG::kLdsWords + 4u, kObufWords = BG::kStageWords;  // (kOutCap + 8 samples fit: NT >= 8)
-    __shared__ __attribute__((aligned(16))) uint32_t lds[kWSize + kObufWords + NT + 2 * NW + 4 + 8];  // (+ s_unit, s_pred, s_next, s_vote[3])
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kWSize + kObufWords + NT + 2 * NW + 4 + 8 + 4 + 3 * NW];  // (+ s_unit, s_pred, s_next, s_vote[3], ..., FUSE: s_F[NW][3])
     uint32_t *const W = lds;
     uint32_t *const stage = lds + kWSize;                        // phase 1: lane-major, kBlkLaneStride dwords per lane
     uint16_t *const obuf = reinterpret_cast<uint16_t *>(stage);  // phase 2: the block's samples in output order
@@ -311,6 +324,7 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
     uint32_t(*const s_tot)[NW] = reinterpret_cast<uint32_t(*)[NW]>(s_e + NT);
     uint64_t *const s_b = reinterpret_cast<uint64_t *>(s_e + NT + 2 * NW);  // (kWSize, kObufWords, NT, 2 NW: all even)
     uint32_t &s_unit = s_e[NT + 2 * NW + 4], &s_pred = s_e[NT + 2 * NW + 5];
+    uint32_t(*const s_F)[3] = reinterpret_cast<uint32_t(*)[3]>(s_e + NT + 2 * NW + 16);  // FUSE: a wavefront's zero-state response
     const uint32_t tid = threadIdx.x;
     const int lane = lane_id(), wv = (int)(tid >> 6);
     uint32_t k = G.k;
@@ -410,6 +424,112 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
             w.w = (a + 3 < pay_hi) ? w.w : 0u;
             // words 4q .. 4q+3 at W[K - 4q - 2 .. K - 4q + 1]: one 16-byte store (K - 4q - 2 = kLdsWords - 4q)
             *reinterpret_cast<uint4 *>(W + (BG::kLdsWords - 4u * qd)) = make_uint4(w.w, w.z, w.y, w.x);
+        }
+    };
+    // ---- FUSE: the inverse filter over the samples [a0, a0 + nsamp) of the staging buffer, in place ----
+    V3 xs{0u, 0u, 0u};  // the state in front of the next sample of the waveform (y[i-1], y[i-2], y[i-3]); thread 0's is the one that counts
+    auto iir_lds = [&](uint32_t a0, uint32_t nsamp) __attribute__((always_inline)) {
+        constexpr uint32_t M = kBlkLaneCap, NP = M / 2u;  // samples / dwords per lane
+        static_assert(NP % 2u == 0u, "a lane's share is moved in 8-byte pieces");
+        if (nsamp == 0u) return;
+        const uint32_t c1 = itab[kRunTabC], c2 = itab[kRunTabC + 1], c3 = itab[kRunTabC + 2], sg = itab[kRunTabC + 3];
+        uint32_t *const mine = reinterpret_cast<uint32_t *>(obuf) + tid * NP;
+        // the recurrence over my run from state s, two dwords (four samples) of LDS at a time -- the run is read once per pass
+        // rather than held in 38 registers across the scan (that form needed 214 registers: two workgroups per CU instead of
+        // three).  Thread 0's first a0 entries lie in front of the block's first sample: no step there.  EMIT: the samples
+        // replace the residuals.
+        uint32_t last2 = 0, last1 = 0;  // EMIT: the run's last two dwords (the last lane may have to go on behind its share)
+        auto run = [&](V3 s0, auto emit_tag) __attribute__((always_inline)) {
+            constexpr bool EMIT = decltype(emit_tag)::value;
+            uint32_t sx = s0.x, sy = s0.y, sz = s0.z;
+            // one dword = two samples; SKIP: the dword may lie in front of the block's first sample (thread 0's first four)
+            // (component by component: a select between two structs is compiled as a select between their ADDRESSES, and the
+            // states went through scratch memory)
+            auto pair = [&](uint32_t dj, uint32_t j, auto skip_tag) __attribute__((always_inline)) {
+                constexpr bool SKIP = decltype(skip_tag)::value;
+                const uint32_t lo = dj & 0xffffu, hi = dj >> 16;
+                uint32_t a = __umul24(lo, sg) + __umul24(c1, sx) + __umul24(c2, sy) + __umul24(c3, sz);
+                if (SKIP) {
+                    const bool skip = tid == 0u && 2u * j < a0;
+                    const uint32_t nx = skip ? sx : a, ny = skip ? sy : sx, nz = skip ? sz : sy;
+                    a = skip ? lo : a;
+                    sx = nx; sy = ny; sz = nz;
+                } else {
+                    sz = sy; sy = sx; sx = a;
+                }
+                uint32_t b = __umul24(hi, sg) + __umul24(c1, sx) + __umul24(c2, sy) + __umul24(c3, sz);
+                if (SKIP) {
+                    const bool skip = tid == 0u && 2u * j + 1u < a0;
+                    const uint32_t nx = skip ? sx : b, ny = skip ? sy : sx, nz = skip ? sz : sy;
+                    b = skip ? hi : b;
+                    sx = nx; sy = ny; sz = nz;
+                } else {
+                    sz = sy; sy = sx; sx = b;
+                }
+                return __builtin_amdgcn_perm(b, a, 0x05040100u);
+            };
+            uint2 w = *reinterpret_cast<const uint2 *>(mine);
+#pragma unroll
+            for (uint32_t j0 = 0; j0 < 4u; j0 += 2u) {  // the first eight samples
+                const uint2 wn = *reinterpret_cast<const uint2 *>(mine + j0 + 2u);
+                const uint32_t o0 = pair(w.x, j0, std::true_type{}), o1 = pair(w.y, j0 + 1u, std::true_type{});
+                if (EMIT) *reinterpret_cast<uint2 *>(mine + j0) = make_uint2(o0, o1);
+                w = wn;
+            }
+            // the rest, the next piece in flight while one is worked on; NOT unrolled further: all 19 loads of a fully unrolled
+            // loop were hoisted to its top (180 registers: two workgroups per CU instead of three)
+#pragma unroll 2
+            for (uint32_t j0 = 4u; j0 < NP; j0 += 2u) {
+                const uint32_t jn = j0 + 2u < NP ? j0 + 2u : j0;
+                const uint2 wn = *reinterpret_cast<const uint2 *>(mine + jn);
+                const uint32_t o0 = pair(w.x, j0, std::false_type{}), o1 = pair(w.y, j0 + 1u, std::false_type{});
+                if (EMIT) {
+                    *reinterpret_cast<uint2 *>(mine + j0) = make_uint2(o0, o1);
+                    last2 = o0; last1 = o1;
+                }
+                w = wn;
+            }
+            return V3{sx, sy, sz};
+        };
+        // pass 1, then the scan: inside the wavefront, then over the wavefronts
+        V3 F = lo16(run(V3{tid == 0u ? xs.x : 0u, tid == 0u ? xs.y : 0u, tid == 0u ? xs.z : 0u}, std::false_type{}));
+#pragma unroll
+        for (int dd = 0; dd < 6; ++dd) {
+            const M3 P = load_m3(itab + kRunTabPL + 9 * dd);  // A^(M 2^dd)
+            const V3 up = shfl_up_v3(F, 1 << dd);
+            if (lane >= (1 << dd)) F = lo16(add(F, mul(P, up)));
+        }
+        V3 E = shfl_up_v3(F, 1);  // the state in front of my run as far as my wavefront knows
+        if (lane == 0) E = V3{0u, 0u, 0u};
+        if (lane == 63) { s_F[wv][0] = F.x; s_F[wv][1] = F.y; s_F[wv][2] = F.z; }
+        blk_barrier();
+        V3 XW{0u, 0u, 0u};  // ... and in front of my wavefront
+        if (NW > 1) {
+            const M3 PW = load_m3(itab + kRunTabPL + 9 * 6);  // A^(64 M)
+            for (int w = 0; w < wv; ++w) XW = lo16(add(mul(PW, XW), V3{s_F[w][0], s_F[w][1], s_F[w][2]}));
+        }
+        V3 S = E;  // (thread 0: the state in front of the block, as in pass 1)
+        if (tid == 0u) { S.x = xs.x; S.y = xs.y; S.z = xs.z; }
+        if (NW > 1 && wv > 0) S = lo16(add(mul(load_m3(itab + kRunTabPLANE + 9 * lane), XW), E));
+        // pass 2: the samples
+        (void)run(S, std::true_type{});
+        // (up to seven samples lie behind the last lane's share when the block's first sample is not 16-byte aligned and the
+        // buffer is full: the last lane goes on, one sample at a time)
+        if (tid == NT - 1u && a0 + nsamp > NT * M) {
+            V3 s{last1 >> 16, last1 & 0xffffu, last2 >> 16};
+            for (uint32_t i = NT * M; i < a0 + nsamp; ++i) {
+                const uint32_t v = (__umul24((uint32_t)obuf[i], sg) + __umul24(c1, s.x) + __umul24(c2, s.y) + __umul24(c3, s.z)) & 0xffffu;
+                obuf[i] = (uint16_t)v;
+                s = V3{v, s.x, s.y};
+            }
+        }
+        blk_barrier();
+        // the state behind these samples: the last three of them (fewer: what was in front moves down)
+        if (tid == 0u) {
+            const uint16_t *e = obuf + (a0 + nsamp);
+            if (nsamp >= 3u) xs = V3{e[-1], e[-2], e[-3]};
+            else if (nsamp == 2u) xs = V3{e[-1], e[-2], xs.x};
+            else xs = V3{e[-1], xs.x, xs.y};
         }
     };
     if (unit >= total_units) return;
@@ -691,6 +811,23 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
                 if (base_c + tot_c != (uint64_t)len || w0 + ((e_end - B0 + 31u) >> 5) != n) atomicExch(suspect + g, 1u);
             }
 
+            // FUSE: the filter's state in front of this block -- zero at the waveform's start, thread 0's own inside a run, the
+            // previous run's last block's across runs (long published where runs of one waveform are not in flight together)
+            if (FUSE && first_of_run && tid == 0u) {
+                xs = V3{0u, 0u, 0u};
+                if (blk > 0u) {
+                    uint64_t v = 0;
+                    uint32_t spins = 0;
+                    for (;;) {
+                        v = __hip_atomic_load(xstate + sidx - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (v >> 63) break;
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > (1u << 24)) { atomicOr(&st->err, kErrInternal); break; }  // cannot happen; never hang
+                    }
+                    xs = V3{(uint32_t)v & 0xffffu, (uint32_t)(v >> 16) & 0xffffu, (uint32_t)(v >> 32) & 0xffffu};
+                }
+            }
+
             // ---- phase 2: the samples in output order, whole lines to HBM ----
             const uint32_t a0 = (uint32_t)((((uintptr_t)(y + blk_first)) >> 1) & 7u);  // kOutCap is a multiple of 8: the same every pass
             auto copy_out = [&](uint32_t R0) __attribute__((always_inline)) {  // staged samples [R0, R0 + kOutCap) of the block -> HBM
@@ -741,6 +878,7 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
                 }
                 blk_barrier();
                 BLK_STAMP(6);  // reorder
+                if (FUSE) iir_lds(a0, blk_count);
                 copy_out(0u);
                 BLK_STAMP(7);  // copy-out
             } else {
@@ -755,10 +893,14 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
                     uint16_t *outp = obuf + (int32_t)(a0 + rel0 - R0);
                     blk_parse<kBlkValue, RESID>(W, k, c < cmax, Qp, 0u, c, acc, cmax, outp);
                     blk_barrier();
+                    if (FUSE) iir_lds(a0, (blk_count - R0 < BG::kOutCap) ? blk_count - R0 : BG::kOutCap);
                     copy_out(R0);
                     blk_barrier();
                 }
             }
+            if (FUSE && last_of_run && tid == 0u)
+                __hip_atomic_store(xstate + sidx, (1ull << 63) | (uint64_t)(xs.x & 0xffffu) | ((uint64_t)(xs.y & 0xffffu) << 16) | ((uint64_t)(xs.z & 0xffffu) << 32),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             blk_barrier();  // W, the staging buffer and the s_* words are rewritten by the next block
             BLK_STAMP(8);
         }
@@ -855,6 +997,14 @@ void blocks_plan_ragged(Geom &G, const ChunkDesc *d, uint32_t *list_out) {
     G.rag_blk_classes = n_cls;
 }
 
+// the fused inverse filter's tables: one set per lane share (76, 68, 60 samples), kRunTabWords each
+uint32_t blocks_iir_tab_words() { return 3u * kRunTabWords; }
+void blocks_iir_tables(const uint32_t fast_nt[3], uint32_t t0neg, uint32_t *tab) {
+    iir_run_tables(fast_nt, t0neg, 76u, tab);
+    iir_run_tables(fast_nt, t0neg, 68u, tab + kRunTabWords);
+    iir_run_tables(fast_nt, t0neg, 60u, tab + 2u * kRunTabWords);
+}
+
 static uint32_t blocks_slots_per_wave(const Geom &G) {  // blocks of a waveform at 25 bits per sample
     if (!G.uniform) return G.rag_blk_slots;
     const uint64_t per = (max_payload_words(G.u_wave_len) + blk_words_min(blocks_nt(G)) - 1u) / blk_words_min(blocks_nt(G));
@@ -862,10 +1012,10 @@ static uint32_t blocks_slots_per_wave(const Geom &G) {  // blocks of a waveform 
 }
 
 constexpr uint32_t kBlkMaxClasses = 32;  // ragged batches: one launch per class of WaveformLengths floor(log2 L)
-// scratch: u32 info[32][4] | u32 fail[W] | u32 suspect[W] | u32 ticket[1] (+ pad to 16 bytes) | u32 ends[slots] | u64 state[slots] | prof
+// scratch: u32 info[32][4] | u32 fail[W] | u32 suspect[W] | u32 ticket[1] (+ pad to 16 bytes) | u32 ends[slots] | u64 state[slots] | u64 xstate[slots] | prof
 struct BlkScratch {
     uint32_t *info, *fail, *suspect, *ticket, *ends;
-    uint64_t *state;
+    uint64_t *state, *xstate;  // xstate: the inverse filter's state behind every block slot (FUSE)
     unsigned long long *prof;  // 16 counters of the diagnostic build
     uint64_t bytes;
 };
@@ -882,8 +1032,9 @@ static BlkScratch blocks_layout(const Geom &G, void *base) {
     L.ends = p + n32;
     const uint64_t ends32 = (U + 1u) & ~1ull;
     L.state = reinterpret_cast<uint64_t *>(L.ends + ends32);
-    L.prof = reinterpret_cast<unsigned long long *>(L.state + U);
-    L.bytes = (n32 + ends32) * 4u + U * 8u + 16u * 8u;
+    L.xstate = L.state + U;
+    L.prof = reinterpret_cast<unsigned long long *>(L.xstate + U);
+    L.bytes = (n32 + ends32) * 4u + 2u * U * 8u + 16u * 8u;
     return L;
 }
 
@@ -891,7 +1042,7 @@ uint64_t blocks_scratch_bytes(const Geom &G) { return blocks_batch(G) ? blocks_l
 
 hipError_t launch_decode_blocks(const Geom &G, const uint32_t *d_in, uint64_t in_words, const uint64_t *d_wave_off,
                                 const uint32_t *d_wave_words, void *d_blk, DevStatus *d_status, int16_t *d_out,
-                                const uint32_t **fail_out, const uint32_t **suspect_out, bool resid, hipStream_t s) {
+                                const uint32_t **fail_out, const uint32_t **suspect_out, bool resid, hipStream_t s, bool *fused_out) {
     const BlkScratch L = blocks_layout(G, d_blk);
     hipError_t e = hipMemsetAsync(d_blk, 0, L.bytes, s);
     if (e != hipSuccess) return e;
@@ -904,6 +1055,18 @@ hipError_t launch_decode_blocks(const Geom &G, const uint32_t *d_in, uint64_t in
 #else
     const int sw = blk_segw_bits10(b10);
 #endif
+    // General filters: the inverse filter inside this kernel (FUSE) where its state can pass from a run's last block to the next
+    // run's first without a chain of waits, i.e. where every launch has at least as many waveforms as resident workgroups (the
+    // condition under which runs are longer than one block); else residuals now and k_iir_tiles behind (debug flag 2097152: always).
+    auto resident_of = [](int nt) { return 256u * (nt == 64 ? 12u : (nt == 128 ? 6u : 3u)); };
+    bool fuse = resid && G.blk_iir_tab != nullptr && !(G.dbg & 2097152u);
+    if (fuse) {
+        if (G.uniform) fuse = G.total_waves >= resident_of(blocks_nt(G));
+        else
+            for (uint32_t c = 0; c < G.rag_blk_classes; ++c)
+                fuse = fuse && (G.rag_blk_class_off[c + 1] - G.rag_blk_class_off[c]) >= resident_of(nt_for_len(G.rag_blk_class_len[c], G.k));
+    }
+    if (fused_out) *fused_out = fuse;
     auto launch_class = [&](uint32_t cls, const uint32_t *list, uint32_t n_waves, int nt, uint32_t wave_len) {
         uint32_t *info = L.info + 4u * cls;
         const uint32_t words_per_block = (uint32_t)nt * (uint32_t)sw;
@@ -914,7 +1077,7 @@ hipError_t launch_decode_blocks(const Geom &G, const uint32_t *d_in, uint64_t in
         // still run when ticket t + n_waves is drawn; the later run's look-back then simply waits on the lower ticket.)  Then as long as the launch keeps kBlkRounds tickets per workgroup (the
         // tail of the last round), up to the whole waveform: only a run's first block waits for other workgroups (nEDM, 6
         // blocks per waveform: one run; NOPTREX, 36: three runs of 12: 1.40 / 0.98 ms against 1.43 / 1.00 with round 2's fixed 4).
-        const uint32_t resident = 256u * (nt == 64 ? 12u : (nt == 128 ? 6u : 3u));
+        const uint32_t resident = resident_of(nt);
         const uint64_t typ_words = ((uint64_t)wave_len * b10) / 320u;
         const uint64_t bpw = (typ_words + words_per_block - 1u) / words_per_block;
         uint64_t rl = ((uint64_t)n_waves * bpw) / ((uint64_t)kBlkRounds * resident);
@@ -922,10 +1085,12 @@ hipError_t launch_decode_blocks(const Geom &G, const uint32_t *d_in, uint64_t in
         const uint32_t run_len = n_waves >= resident ? (uint32_t)(rl < 1u ? 1u : rl) : 1u;
         auto go = [&](auto nt_tag, auto resid_tag, auto sw_tag, unsigned per_cu) {
             constexpr int NT = decltype(nt_tag)::value, SW = decltype(sw_tag)::value;
-            constexpr bool RESID = decltype(resid_tag)::value;
+            constexpr int MODE = decltype(resid_tag)::value;  // 0 delta filter, 1 residuals (k_iir_tiles follows), 2 inverse filter fused
             const unsigned grid = (unsigned)(units < 256u * per_cu ? units : 256u * per_cu);
-            k_decode_blocks<NT, RESID, SW><<<grid, NT, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, info, spw, run_len, L.state, L.ends,
-                                                               info + 2, L.fail, L.suspect, d_status, d_out, L.prof, list, n_waves);
+            // the filter's tables for runs of this geometry's lane share (76 / 68 / 60 samples)
+            const uint32_t *itab = G.blk_iir_tab ? G.blk_iir_tab + kRunTabWords * (blk_lane_cap(SW) == 76u ? 0u : (blk_lane_cap(SW) == 68u ? 1u : 2u)) : nullptr;
+            k_decode_blocks<NT, MODE != 0, SW, MODE == 2><<<grid, NT, 0, s>>>(G, d_in, in_words, d_wave_off, d_wave_words, info, spw, run_len, L.state, L.ends,
+                                                                             info + 2, L.fail, L.suspect, d_status, d_out, L.prof, list, n_waves, itab, L.xstate);
         };
         auto by_sw = [&](auto nt_tag, auto resid_tag, unsigned per_cu) {
             switch (sw) {
@@ -936,7 +1101,9 @@ hipError_t launch_decode_blocks(const Geom &G, const uint32_t *d_in, uint64_t in
             }
         };
         auto by_resid = [&](auto nt_tag, unsigned per_cu) {
-            if (resid) by_sw(nt_tag, std::true_type{}, per_cu); else by_sw(nt_tag, std::false_type{}, per_cu);
+            if (fuse) by_sw(nt_tag, std::integral_constant<int, 2>{}, per_cu);
+            else if (resid) by_sw(nt_tag, std::integral_constant<int, 1>{}, per_cu);
+            else by_sw(nt_tag, std::integral_constant<int, 0>{}, per_cu);
         };
         // resident workgroups per CU by LDS: 50 dwords per lane in every class
         if (nt == 64) by_resid(std::integral_constant<int, 64>{}, 12u);

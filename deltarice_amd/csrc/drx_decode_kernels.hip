@@ -1327,13 +1327,14 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
         // a workgroup per block of every waveform (drx_blocks.hip); waveforms it flags are decoded again, one
         // workgroup each, by the kernel that also judges them
         const uint32_t *fail = nullptr, *suspect = nullptr;
-        path |= 4u | (gen ? 32u : 0u);  // DRX_PATH_BLOCKS (| DRX_PATH_IIR)
-        hipError_t e = launch_decode_blocks(G, d_in, in_words, d_wave_off, d_wave_words, d_blk, d_status, d_out, &fail, &suspect, gen, s);
+        bool fused = false;
+        hipError_t e = launch_decode_blocks(G, d_in, in_words, d_wave_off, d_wave_words, d_blk, d_status, d_out, &fail, &suspect, gen, s, &fused);
         if (e != hipSuccess) return e;
+        path |= 4u | (gen ? (fused ? 64u : 32u) : 0u);  // DRX_PATH_BLOCKS (| DRX_PATH_IIR_FUSED / DRX_PATH_IIR)
         k_decode_long<<<(unsigned)G.total_waves, kLongThreads, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_status, d_out, fail, suspect, gen ? 1u : 0u);
         if (gen) {
-            // residuals -> samples, in place; then the waveforms the block decoder flagged, serially (a slope-1 ramp)
-            if ((e = launch_iir(G, G.iir_chunk_tile_base, G.iir_n_tiles, G.iir_tab, G.iir_state, fail, d_status, d_out, s)) != hipSuccess) return e;
+            // (not fused: residuals -> samples, in place;) then the waveforms the block decoder flagged, serially (a slope-1 ramp)
+            if (!fused && (e = launch_iir(G, G.iir_chunk_tile_base, G.iir_n_tiles, G.iir_tab, G.iir_state, fail, d_status, d_out, s)) != hipSuccess) return e;
             k_decode_simple<<<nb_plain, 64, 0, s>>>(G, d_in, d_wave_off, d_wave_words, d_status, d_out, fail);
         }
         break;

@@ -30,6 +30,7 @@
 
 #include "drx_device.h"
 #include "drx_internal.h"
+#include "drx_iir_math.h"
 
 namespace drx {
 
@@ -37,35 +38,6 @@ namespace drx {
 constexpr uint32_t kIirPL = 0, kIirPLANE = 7 * 9, kIirPTP = kIirPLANE + 64 * 9, kIirC = kIirPTP + (kIirWin + 1) * 9;
 static_assert(kIirC + 4 == kIirTabWords, "table layout");
 
-struct V3 { uint32_t x, y, z; };
-struct M3 { uint32_t m[9]; };
-__device__ __forceinline__ M3 load_m3(const uint32_t *__restrict__ t) {
-    M3 r;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) r.m[i] = t[i];
-    return r;
-}
-__device__ __forceinline__ V3 mul(const M3 &a, const V3 &v) {
-    V3 r;
-    r.x = __umul24(a.m[0], v.x) + __umul24(a.m[1], v.y) + __umul24(a.m[2], v.z);
-    r.y = __umul24(a.m[3], v.x) + __umul24(a.m[4], v.y) + __umul24(a.m[5], v.z);
-    r.z = __umul24(a.m[6], v.x) + __umul24(a.m[7], v.y) + __umul24(a.m[8], v.z);
-    return r;
-}
-__device__ __forceinline__ M3 mul(const M3 &a, const M3 &b) {
-    M3 r;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            r.m[3 * i + j] = (__umul24(a.m[3 * i], b.m[j]) + __umul24(a.m[3 * i + 1], b.m[3 + j]) + __umul24(a.m[3 * i + 2], b.m[6 + j])) & 0xffffu;
-    return r;
-}
-__device__ __forceinline__ V3 add(const V3 &a, const V3 &b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
-__device__ __forceinline__ V3 lo16(const V3 &a) { return V3{a.x & 0xffffu, a.y & 0xffffu, a.z & 0xffffu}; }
-__device__ __forceinline__ V3 shfl_up_v3(const V3 &a, int d) {
-    return V3{(uint32_t)__shfl_up((int)a.x, d), (uint32_t)__shfl_up((int)a.y, d), (uint32_t)__shfl_up((int)a.z, d)};
-}
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d);

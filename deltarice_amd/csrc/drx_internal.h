@@ -46,6 +46,7 @@ struct Geom {
                    //  131072 ragged batches: one decode launch behind both header walks instead of one behind each
                    //  262144 k_encode_stream on three workgroups (tests: every wavefront goes around its ring)
                    //  524288 k_encode_stream (encode_impl 2) whatever the batch (else: where stream_encoder_suits())
+                   //  2097152 general filters behind the block decoder: always the separate k_iir_tiles pass
                    // Ablation switches INSIDE the kernels, compiled only with -DDRX_ABLATION (results invalid):
                    //   decode:   1 skip the output stores   2 skip the stream loads
                    //             4 request pieces without counting on the round's minimum consumption   16384 long: no stores
@@ -67,6 +68,7 @@ struct Geom {
     uint32_t rag_blk_class_off[33], rag_blk_class_len[32];
     // general prediction filter behind the block decoder (drx_iir.hip): tables, tiles and their look-back state
     const uint32_t *iir_tab;
+    const uint32_t *blk_iir_tab;  // ... and inside the block decoder (FUSE): blocks_iir_tables()
     const uint64_t *iir_chunk_tile_base;  // ragged: first tile of every chunk, n_chunks + 1 entries
     uint64_t iir_n_tiles;
     uint64_t *iir_state;                  // uint64[iir_n_tiles + 1]
@@ -161,9 +163,12 @@ bool blocks_batch(const Geom &G);
 void blocks_plan_ragged(Geom &G, const ChunkDesc *host_chunks, uint32_t *list_out);
 uint64_t blocks_scratch_bytes(const Geom &G);
 // resid: leave the residuals (not their running sums) in d_out: a general prediction filter's inverse follows (launch_iir)
+// fused_out: a general filter's inverse ran inside the kernel (no k_iir_tiles pass is needed behind it)
 hipError_t launch_decode_blocks(const Geom &G, const uint32_t *d_in, uint64_t in_words, const uint64_t *d_wave_off,
                                 const uint32_t *d_wave_words, void *d_blk, DevStatus *d_status, int16_t *d_out,
-                                const uint32_t **fail_out, const uint32_t **suspect_out, bool resid, hipStream_t s);
+                                const uint32_t **fail_out, const uint32_t **suspect_out, bool resid, hipStream_t s, bool *fused_out);
+uint32_t blocks_iir_tab_words();
+void blocks_iir_tables(const uint32_t fast_nt[3], uint32_t t0neg, uint32_t *tab);
 // single-pass encoder for short and long waveforms (drx_pieces.hip): a wavefront takes a PIECE, either a run of whole
 // short waveforms or one segment of a long one; the pieces of a chunk fill whole workgroups of kPcWaves wavefronts
 constexpr uint32_t kPcWaves = 8;

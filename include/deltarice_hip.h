@@ -150,6 +150,7 @@ const uint64_t *drx_plan_wave_word_off(const drx_plan *plan);
 #define DRX_PATH_LONG 8u        /* a workgroup per waveform */
 #define DRX_PATH_SIMPLE 16u     /* the simple kernel (filters the fast kernels do not take) */
 #define DRX_PATH_IIR 32u        /* residuals first, then the general filter's inverse in place, parallel inside a waveform */
+#define DRX_PATH_IIR_FUSED 64u  /* the general filter's inverse inside the block decoder: one kernel, samples straight to the output */
 uint32_t drx_plan_last_decode_path(const drx_plan *plan);
 /* Copies n_i of every waveform to host memory (waits for the stream). */
 drx_status drx_plan_read_wave_words(drx_plan *plan, uint32_t *host_out);
@@ -184,7 +185,8 @@ drx_status drx_plan_last_timings(drx_plan *plan, float ms[4]);
  *        4096 never the pieces encoder, 8192 always the segment encoder, 32768 the pieces encoder also where one wavefront per
  *        waveform is the default, 65536 never the single-pass encoder's larger-buffer geometries (RiceParameter above 8),
  *        262144 the persistent encoder on three workgroups (every wavefront codes many waveforms of a small batch),
- *        524288 the persistent encoder (encode_impl 2) whatever the batch's size and expected code length.  (Ablation switches inside the kernels exist only in -DDRX_ABLATION builds.) */
+ *        524288 the persistent encoder (encode_impl 2) whatever the batch's size and expected code length,
+ *        2097152 general filters behind the block decoder: always the separate inverse-filter pass.  (Ablation switches inside the kernels exist only in -DDRX_ABLATION builds.) */
 drx_status drx_ctx_set_option(drx_ctx *ctx, const char *key, int64_t value);
 
 #ifdef __cplusplus

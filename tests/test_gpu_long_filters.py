@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 
-BLOCKS, IIR, LANES_ANY = 4, 32, 1 | 2
+BLOCKS, IIR, IIR_FUSED, LANES_ANY = 4, 32, 64, 1 | 2
 
 
 @pytest.fixture(scope="module")
@@ -67,6 +67,51 @@ def test_general_filter_few_long_waveforms_uniform(ctx, O):
             enc2 = plan.encode(dev(ctx, x))
             w2, off2 = enc2.to_numpy()
             assert np.array_equal(off2, ref_off) and np.array_equal(w2, ref_w)
+
+
+def test_general_filter_many_long_waveforms_fused(ctx, O):
+    """Batches with at least as many long waveforms as the block decoder keeps workgroups resident (NOPTREX-shaped: 64 chunks
+    of 32 x 500 000; nEDM: 256 x 32 x 81 920): the inverse filter runs INSIDE the block decoder (round 4: one kernel, samples
+    straight to the output; DRX_PATH_IIR_FUSED), its state handed from block to block and from run to run of a waveform.
+    Held to the oracle's stream, to the two-pass form (flag 2097152) and to the lane-per-waveform decoder (flag 256): one, two
+    and three blocks per waveform, runs of two blocks, odd WaveformLengths (the staging buffer's first sample then sits
+    anywhere in its 16-byte piece), a shorter last waveform, quiet data (more samples per lane than its share: staging
+    passes), loud data, the lane classes of 64 / 128 / 256 lanes per block."""
+    import deltarice_amd as dr
+    rng = np.random.default_rng(404)
+    shapes = [(8, 100, 30011, 3, "gauss10"),      # 800 waveforms, 256 lanes, three blocks each, every block a run of its own
+              (4, 1050, 30000, 3, "gauss10"),     # 4200 waveforms: runs of two blocks
+              (2, 800, 9001, 3, "gauss10"),       # one block per waveform
+              (2, 1600, 6000, 3, "gauss10"),      # 128 lanes per block
+              (2, 1600, 3000, 3, "gauss10"),      # 64 lanes
+              (3, 300, 20000, 3, "steps"),        # quiet: 4 bits per sample
+              (2, 450, 16385, 8, "gauss300"),     # loud under a RiceParameter that suits it
+              (1, 801, 25000, 3, "zeros")]
+    for si, (n_chunks, W, L, k, kind) in enumerate(shapes):
+        N = W * L - (L // 3)  # a shorter last waveform
+        x = make_data(rng, kind, n_chunks * N)
+        for taps in (TAPS if si == 0 else [TAPS[0], TAPS[3]]):
+            opts = (1 << k, L, len(taps)) + u32(taps)
+            plan = ctx.plan_uniform(n_chunks, N, opts)
+            enc = plan.encode(dev(ctx, x))
+            if si in (0, 2):
+                ref_w, ref_off = O.encode_batch(x, N, opts)
+                w, off = enc.to_numpy()
+                assert np.array_equal(off, ref_off) and np.array_equal(w, ref_w), (si, taps)
+            outs = {}
+            for flags in (0, 2097152, 256):
+                ctx.set_option("debug_flags", flags)
+                outs[flags] = plan.decode(enc).cpu().numpy()
+                path = plan.last_decode_path()
+                ctx.set_option("debug_flags", 0)
+                if flags == 0:
+                    assert path & BLOCKS and path & IIR_FUSED and not path & IIR, (path, W, L)
+                elif flags == 2097152:
+                    assert path & BLOCKS and path & IIR and not path & IIR_FUSED, (path, W, L)
+                else:
+                    assert path & LANES_ANY and not path & BLOCKS, (path, W, L)
+            for flags, y in outs.items():
+                assert np.array_equal(y, x), (n_chunks, W, L, k, kind, taps, flags, int(np.argmax(y != x)))
 
 
 def test_general_filter_ramp_falls_back_and_is_exact(ctx, O):

@@ -1059,15 +1059,19 @@ hipError_t launch_decode_blocks(const Geom &G, const uint32_t *d_in, uint64_t in
     // run's first without a chain of waits, i.e. where every launch has at least as many waveforms as resident workgroups (the
     // condition under which runs are longer than one block); else residuals now and k_iir_tiles behind (debug flag 2097152: always).
     auto resident_of = [](int nt) { return 256u * (nt == 64 ? 12u : (nt == 128 ? 6u : 3u)); };
+    // (General filters run at 128 or 256 lanes per block when fused and at 256 when not: 12 of the 36 instantiations of the
+    // kernel are not built; a block larger than the class's choice costs short waveforms some empty lanes, nothing else.)
+    auto nt_gen = [](int nt) { return nt < 128 ? 128 : nt; };
     bool fuse = resid && G.blk_iir_tab != nullptr && !(G.dbg & 2097152u);
     if (fuse) {
-        if (G.uniform) fuse = G.total_waves >= resident_of(blocks_nt(G));
+        if (G.uniform) fuse = G.total_waves >= resident_of(nt_gen(blocks_nt(G)));
         else
             for (uint32_t c = 0; c < G.rag_blk_classes; ++c)
-                fuse = fuse && (G.rag_blk_class_off[c + 1] - G.rag_blk_class_off[c]) >= resident_of(nt_for_len(G.rag_blk_class_len[c], G.k));
+                fuse = fuse && (G.rag_blk_class_off[c + 1] - G.rag_blk_class_off[c]) >= resident_of(nt_gen(nt_for_len(G.rag_blk_class_len[c], G.k)));
     }
     if (fused_out) *fused_out = fuse;
     auto launch_class = [&](uint32_t cls, const uint32_t *list, uint32_t n_waves, int nt, uint32_t wave_len) {
+        if (resid) nt = fuse ? nt_gen(nt) : 256;
         uint32_t *info = L.info + 4u * cls;
         const uint32_t words_per_block = (uint32_t)nt * (uint32_t)sw;
         k_blk_max<<<1, 1024, 0, s>>>(n_waves, d_wave_words, words_per_block, info, list);
@@ -1106,8 +1110,9 @@ hipError_t launch_decode_blocks(const Geom &G, const uint32_t *d_in, uint64_t in
             else by_sw(nt_tag, std::integral_constant<int, 0>{}, per_cu);
         };
         // resident workgroups per CU by LDS: 50 dwords per lane in every class
-        if (nt == 64) by_resid(std::integral_constant<int, 64>{}, 12u);
-        else if (nt == 128) by_resid(std::integral_constant<int, 128>{}, 6u);
+        auto delta_only = [&](auto nt_tag, unsigned per_cu) { by_sw(nt_tag, std::integral_constant<int, 0>{}, per_cu); };
+        if (nt == 64) delta_only(std::integral_constant<int, 64>{}, 12u);
+        else if (nt == 128) { if (fuse) by_sw(std::integral_constant<int, 128>{}, std::integral_constant<int, 2>{}, 6u); else delta_only(std::integral_constant<int, 128>{}, 6u); }
         else by_resid(std::integral_constant<int, 256>{}, 3u);
     };
     if (G.uniform) {

@@ -660,6 +660,9 @@ static drx_status decode_launch(drx_plan *p, const uint32_t *d_in, uint64_t in_w
     DRX_ON_DEVICE(ctx);
     DRX_HIP(ctx, hipMemsetAsync(p->d_status, 0, sizeof(DevStatus), ctx->stream));
     p->G.dbg = ctx->debug_flags;
+    // (a stream of this plan's geometry also says how long a waveform's code is: the next encode's kernel is chosen by it,
+    // stream_encoder_suits() -- callers that never wait for an encode, like bench.py's steps, are covered this way)
+    if (p->G.total_waves) p->enc_words_per_wave = in_words / p->G.total_waves;
     if (d_sideband) {  // header positions from the caller's n_i table, checked against the stream (k_sideband_tables)
         DRX_HIP(ctx, launch_sideband_tables(p->G, d_in, in_words, d_chunk_word_off, d_sideband, p->d_wave_off, p->d_wave_words,
                                             p->d_status, ctx->stream));

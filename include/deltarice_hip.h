@@ -97,9 +97,13 @@ drx_status drx_plan_create(drx_ctx *ctx, uint64_t n_chunks, const uint32_t *chun
                            const uint32_t *chunk_wave_len, uint32_t rice_k, drx_plan **out);
 drx_status drx_plan_create_uniform(drx_ctx *ctx, uint64_t n_chunks, uint32_t chunk_samples,
                                    uint32_t wave_len, uint32_t rice_k, drx_plan **out);
-/* Prediction filter of the plan (cd_values[2..], src/deltaRice.c:277-289).  Default: the delta
- * filter [1,-1], served by the fast kernels; any other taps (1 <= n_taps <= DRX_MAX_TAPS,
- * taps[0] != 0) select general FIR/IIR kernels on the GPU (correct, not tuned). */
+/* Prediction filter of the plan (cd_values[2..], src/deltaRice.c:277-289).  Default: the delta filter [1,-1].  Any other
+ * taps (1 <= n_taps <= DRX_MAX_TAPS, taps[0] != 0) run on the GPU as well:
+ *   up to four taps            the single-pass encoders' own kernels (forward filter in packed 16-bit math);
+ *   ... and taps[0] = +-1      the fast decoders: a lane per waveform with the recurrence in the lane, or -- few long waveforms --
+ *                              the block decoder with the inverse filter inside it (DRX_PATH_IIR_FUSED) or as a parallel pass of
+ *                              its own behind it (DRX_PATH_IIR);
+ *   anything else              the two-pass encoder and the simple decode kernel (DRX_PATH_SIMPLE): a lane per waveform, serial. */
 drx_status drx_plan_set_filter(drx_plan *plan, uint32_t n_taps, const int32_t *taps);
 void drx_plan_destroy(drx_plan *plan);
 uint64_t drx_plan_n_chunks(const drx_plan *plan);

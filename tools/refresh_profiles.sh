@@ -3,7 +3,7 @@
 # command, and the two PMC passes for HBM traffic.  Run from the repo root on the GPU box (gpurun).
 # usage: tools/refresh_profiles.sh [TAG]   (default r02; output in gpurun_out/refresh, to be copied into profiles/)
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/refresh

@@ -536,6 +536,7 @@ __global__ __launch_bounds__(64) void k_walk_block(Geom G, const uint32_t *__res
 // table written straight from LDS -- was built and measured SLOWER than the two passes, 0.97 against 0.88 ms on config 5:
 // the frontier of known prefixes advances one window of entries per memory round trip; profiles/r02_notes.md.)
 constexpr uint32_t kBwTries = 6;  // impostors tolerated in front of a block's first real header
+constexpr uint32_t kBwCandCap = 512;  // the fast path's room for a block's headers (more: the chase)
 constexpr uint32_t kBwMaxList = 256;  // chunks per launch (bw_walk_blocks_max() / the plan admit at most 224)
 
 struct BwBlock { uint32_t entry, count, exit, base; };
@@ -575,52 +576,160 @@ __global__ __launch_bounds__(64) void k_bw_blocks(Geom G, const uint32_t *__rest
     constexpr int NV = B / 256;
     __shared__ __attribute__((aligned(16))) uint32_t blk[B];
     __shared__ uint16_t hop[EMIT ? B / 2 : 2];  // header positions inside the block (a waveform has at least one payload word)
+    __shared__ uint16_t cand[EMIT ? 2 : kBwCandCap];  // the fast path's candidates, in position order
     __shared__ uint32_t pre[kBwMaxList + 1];
     const int lane = lane_id();
     bw_block_prefix<B>(chunk_word_off, in_words, list, n_list, blocks_max, pre, lane);
     const uint32_t total = pre[n_list];
-    for (uint32_t unit = blockIdx.x; unit < total; unit += gridDim.x) {
-        wave_sync();  // (the previous block's LDS reads are done)
+    // A block at a time per wavefront, the NEXT block's words in flight (registers) while the current one is worked on in LDS:
+    // without that a unit was a chain of dependent latencies -- chunk table, 8 KB of loads, the LDS work, the stores --
+    // of ~3.5 us, and 84 units per wavefront were the kernel's 0.3 ms on config 5 whatever the chase cost (round 4).
+    struct Unit {
+        bool ok;
+        uint64_t c, begin, wbase;
+        uint32_t b, b0, len_w, blk_len, W, L, n_samples;
+    };
+    uint32_t cached_slot = 0xffffffffu;
+    Unit cached{};
+    auto locate_unit = [&](uint32_t unit) __attribute__((always_inline)) {
         uint32_t lo = 0, hi = n_list;  // invariant: pre[lo] <= unit < pre[hi]
         while (hi - lo > 1u) {
             const uint32_t mid = (lo + hi) >> 1;
             if (pre[mid] <= unit) lo = mid; else hi = mid;
         }
-        const uint32_t slot = lo, b = unit - pre[lo];
-        const uint64_t c = list ? (uint64_t)list[slot] : slot;
-        if (EMIT && fail[c]) continue;
-        uint32_t W, L, n_samples;
-        uint64_t wbase;
-        if (G.uniform) { W = G.u_n_waves; L = G.u_wave_len; n_samples = G.u_n_samples; wbase = c * W; }
-        else { const ChunkDesc d = G.chunks[c]; W = d.n_waves; L = d.wave_len; n_samples = d.n_samples; wbase = d.wave_base; }
-        const uint64_t begin = chunk_word_off[c], end = chunk_word_off[c + 1];
-        const uint32_t len_w = (uint32_t)(end - begin);  // (a chunk with an unusable extent has no blocks)
-        const uint32_t b0 = b * B;  // block = words [b0, b0 + B) of the chunk
-        if (b0 >= len_w) continue;   // (only a chunk cut at the host's bound; flagged by k_bw_scan)
-        const uint32_t blk_len = len_w - b0 < B ? len_w - b0 : B;
+        const uint32_t slot = lo;
+        if (slot != cached_slot) {  // (a wavefront's consecutive units mostly lie in one chunk: its table entry is read once)
+            cached_slot = slot;
+            const uint64_t cc = list ? (uint64_t)list[slot] : slot;
+            cached.c = cc;
+            if (G.uniform) { cached.W = G.u_n_waves; cached.L = G.u_wave_len; cached.n_samples = G.u_n_samples; cached.wbase = cc * cached.W; }
+            else { const ChunkDesc d = G.chunks[cc]; cached.W = d.n_waves; cached.L = d.wave_len; cached.n_samples = d.n_samples; cached.wbase = d.wave_base; }
+            cached.begin = chunk_word_off[cc];
+            cached.len_w = (uint32_t)(chunk_word_off[cc + 1] - cached.begin);  // (a chunk with an unusable extent has no blocks)
+            cached.ok = !(EMIT && fail[cc]);
+        }
+        Unit u = cached;
+        u.b = unit - pre[slot];
+        u.b0 = u.b * B;  // block = words [b0, b0 + B) of the chunk
+        if (u.b0 >= u.len_w) u.ok = false;  // (only a chunk cut at the host's bound; flagged by k_bw_scan)
+        u.blk_len = u.ok ? (u.len_w - u.b0 < B ? u.len_w - u.b0 : B) : 0u;
+        return u;
+    };
+    // the block's words: unconditional 16-byte loads (any 4-byte alignment: a chunk starts anywhere) from an address clamped
+    // into the stream; what the clamp moved and what lies behind the block is sorted out when the registers go to LDS
+    const int64_t a_max = (int64_t)in_words - 4;
+    auto fetch = [&](const Unit &u, uint4 (&v)[NV]) __attribute__((always_inline)) {
+        const int64_t a0 = (int64_t)(u.begin + u.b0);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int64_t a = a0 + (int64_t)((uint32_t)(j * 64 + lane) * 4u);
+            const int64_t ac = a > a_max ? (a_max < 0 ? 0 : a_max) : a;
+            v[j] = *reinterpret_cast<const uint4 *>(in + ac);
+        }
+    };
+    auto store = [&](const Unit &u, const uint4 (&v)[NV]) __attribute__((always_inline)) {
+        const uint64_t a0 = u.begin + u.b0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const uint32_t i = (uint32_t)(j * 64 + lane) * 4u;
+            uint4 w = v[j];
+            if ((int64_t)(a0 + i) > a_max) {  // the clamp moved this piece (the last words of the batch): word by word
+                auto ld = [&](uint64_t q) { return q < in_words ? in[q] : 0xffffffffu; };
+                w = make_uint4(ld(a0 + i), ld(a0 + i + 1u), ld(a0 + i + 2u), ld(a0 + i + 3u));
+            }
+            w.x = (i + 0u < u.blk_len) ? w.x : 0xffffffffu;
+            w.y = (i + 1u < u.blk_len) ? w.y : 0xffffffffu;
+            w.z = (i + 2u < u.blk_len) ? w.z : 0xffffffffu;
+            w.w = (i + 3u < u.blk_len) ? w.w : 0xffffffffu;
+            *reinterpret_cast<uint4 *>(blk + i) = w;
+        }
+    };
+    uint4 img[NV];
+    Unit cur{};
+    cur.ok = false;
+    if (blockIdx.x < total) { cur = locate_unit(blockIdx.x); if (cur.ok) fetch(cur, img); }
+    for (uint32_t unit = blockIdx.x; unit < total; unit += gridDim.x) {
+        wave_sync();  // (the previous block's LDS reads are done)
+        const Unit me_u = cur;
+        if (me_u.ok) store(me_u, img);
+        if (unit + gridDim.x < total) { cur = locate_unit(unit + gridDim.x); if (cur.ok) fetch(cur, img); }
+        if (!me_u.ok) continue;
+        const uint64_t c = me_u.c, begin = me_u.begin, wbase = me_u.wbase;
+        const uint32_t b = me_u.b, b0 = me_u.b0, len_w = me_u.len_w, blk_len = me_u.blk_len, W = me_u.W, L = me_u.L, n_samples = me_u.n_samples;
         const uint32_t max_full = (uint32_t)(((uint64_t)L * 25u + 31u) >> 5);
         const uint32_t min_words = min_payload_words(L, G.k);
-        // the block's words into LDS (a fixed grid of 16-byte quads relative to the block)
-        {
-            const uint64_t a0 = begin + b0;
-            const bool vec_ok = (((uintptr_t)(in + a0)) & 15u) == 0;
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const uint32_t i = (uint32_t)(j * 64 + lane) * 4u;
-                uint4 v;
-                if (vec_ok && i + 4u <= blk_len) {
-                    v = *reinterpret_cast<const uint4 *>(in + a0 + i);
-                } else {
-                    v.x = (i + 0u < blk_len) ? in[a0 + i + 0u] : 0xffffffffu;
-                    v.y = (i + 1u < blk_len) ? in[a0 + i + 1u] : 0xffffffffu;
-                    v.z = (i + 2u < blk_len) ? in[a0 + i + 2u] : 0xffffffffu;
-                    v.w = (i + 3u < blk_len) ? in[a0 + i + 3u] : 0xffffffffu;
-                }
-                *reinterpret_cast<uint4 *>(blk + i) = v;
-            }
-        }
+        (void)c; (void)wbase; (void)W; (void)n_samples; (void)begin; (void)min_words;
         wave_sync();
         if (!EMIT) {
+            // FAST PATH (round 4).  A payload word is 32 bits of dense code: it lies in [1, max_words] (400 for WaveformLength
+            // 512) about once in ten million words, so the block's words in that range ARE its headers, nearly always.  All of
+            // them are found at once (the block is read 16 bytes per lane and step, as below), put in position order by ballots,
+            // and held to the chain's own equalities in parallel: every candidate's position + n + 1 must be the next
+            // candidate's position, the last one's must leave the block.  One impostor (or a header beyond the list's room)
+            // and the block takes the chase below, as before.  The chase is one lane following ~20 dependent LDS reads per
+            // 2048-word block while 63 lanes wait: 0.13 us per hop, 0.33 ms for config 5's 278 000 blocks (profiles/r04_notes.md section 5).
+            {
+                const uint32_t from0 = b == 0 ? 1u : 0u;
+                uint32_t ncand = 0;
+                bool overflow = false;
+                for (uint32_t base = 0; base < blk_len; base += 256u) {
+                    const uint32_t i = base + 4u * (uint32_t)lane;
+                    const uint4 v = *reinterpret_cast<const uint4 *>(blk + i);  // (all B words were written above)
+                    const bool f0 = i + 0u >= from0 && i + 0u < blk_len && v.x - 1u < max_full;
+                    const bool f1 = i + 1u >= from0 && i + 1u < blk_len && v.y - 1u < max_full;
+                    const bool f2 = i + 2u >= from0 && i + 2u < blk_len && v.z - 1u < max_full;
+                    const bool f3 = i + 3u >= from0 && i + 3u < blk_len && v.w - 1u < max_full;
+                    const uint64_t m0 = __ballot(f0), m1 = __ballot(f1), m2 = __ballot(f2), m3 = __ballot(f3);
+                    if ((m0 | m1 | m2 | m3) == 0ull) continue;
+                    const uint64_t below = (1ull << lane) - 1ull;
+                    // candidates of lower lanes come first, then this lane's own in component order
+                    uint32_t r = ncand + (uint32_t)(__builtin_popcountll(m0 & below) + __builtin_popcountll(m1 & below) +
+                                                    __builtin_popcountll(m2 & below) + __builtin_popcountll(m3 & below));
+                    if (f0) { if (r < kBwCandCap) cand[r] = (uint16_t)(i + 0u); ++r; }
+                    if (f1) { if (r < kBwCandCap) cand[r] = (uint16_t)(i + 1u); ++r; }
+                    if (f2) { if (r < kBwCandCap) cand[r] = (uint16_t)(i + 2u); ++r; }
+                    if (f3) { if (r < kBwCandCap) cand[r] = (uint16_t)(i + 3u); ++r; }
+                    ncand += (uint32_t)(__builtin_popcountll(m0) + __builtin_popcountll(m1) + __builtin_popcountll(m2) + __builtin_popcountll(m3));
+                    overflow = overflow || ncand > kBwCandCap;
+                }
+                wave_sync();
+                bool fast = ncand != 0u && !overflow && (!LIST || ncand <= hop_cap);
+                uint32_t exit_rel = 0;
+                if (fast) {
+                    bool bad = false;
+                    for (uint32_t j0 = 0; j0 < ncand; j0 += 64u) {
+                        const uint32_t j = j0 + (uint32_t)lane;
+                        if (j < ncand) {
+                            const uint32_t pos = cand[j], n = blk[pos], nxt = pos + n + 1u;
+                            // (as in the chase: the waveform must end inside the chunk; LIST: not below 1 + k bits per sample
+                            // unless it is the chunk's last)
+                            if ((uint64_t)b0 + nxt > len_w) bad = true;
+                            if (LIST && n < min_words && b0 + nxt != len_w) bad = true;
+                            if (j + 1u < ncand) { if (nxt != (uint32_t)cand[j + 1u]) bad = true; }
+                            else { if (nxt < blk_len) bad = true; exit_rel = nxt; }
+                        }
+                    }
+                    fast = !__any(bad);
+                }
+                if (fast) {
+                    exit_rel = (uint32_t)__builtin_amdgcn_readlane((int)exit_rel, (int)((ncand - 1u) & 63u));
+                    if (LIST) {
+                        for (uint32_t j = (uint32_t)lane; j < ncand; j += 64u) {
+                            const uint32_t pos = cand[j];
+                            hops[(uint64_t)unit * hop_cap + j] = pos | (blk[pos] << 12);
+                        }
+                    }
+                    if (lane == 0) {
+                        BwBlock o;
+                        o.entry = b0 + (uint32_t)cand[0];
+                        o.count = ncand;
+                        o.exit = b0 + exit_rel;
+                        o.base = 0;
+                        info[unit] = o;
+                    }
+                    continue;
+                }
+            }
             // candidates in position order: the first word in [1, max_words] at or after `from` (word 0 of the chunk is its
             // sample count: block 0 starts at word 1), 256 words per step.  Never 0: a waveform has at least one payload
             // word, while the zero-padded LAST word of a waveform is all zeros whenever its final code ends in zero bits --
@@ -766,7 +875,10 @@ __global__ __launch_bounds__(256) void k_bw_emit(Geom G, uint64_t in_words, cons
     if (wv == 0) bw_block_prefix<B>(chunk_word_off, in_words, list, n_list, blocks_max, pre, lane);
     __syncthreads();
     const uint32_t total = pre[n_list];
-    for (uint32_t unit = blockIdx.x * 4u + wv; unit < total; unit += gridDim.x * 4u) {
+    // A LANE per block (round 4; a wavefront per block before): a block holds ~20 headers, so 44 lanes of a wavefront had
+    // nothing to do, and every block paid its chain of dependent loads (list, table entry, info) alone -- 0.12-0.14 ms on
+    // config 5 for 11 MB of table.  64 blocks' chains now travel together.
+    for (uint32_t unit = blockIdx.x * 256u + threadIdx.x; unit < total; unit += gridDim.x * 256u) {
         uint32_t lo = 0, hi = n_list;  // invariant: pre[lo] <= unit < pre[hi]
         while (hi - lo > 1u) {
             const uint32_t mid = (lo + hi) >> 1;
@@ -782,8 +894,9 @@ __global__ __launch_bounds__(256) void k_bw_emit(Geom G, uint64_t in_words, cons
         if (G.uniform) { W = G.u_n_waves; L = G.u_wave_len; n_samples = G.u_n_samples; wbase = c * W; }
         else { const ChunkDesc d = G.chunks[c]; W = d.n_waves; L = d.wave_len; n_samples = d.n_samples; wbase = d.wave_base; }
         const uint64_t at = chunk_word_off[c] + (uint64_t)b * B;
-        for (uint32_t i = (uint32_t)lane; i < me.count; i += 64u) {
-            const uint32_t h = hops[(uint64_t)unit * hop_cap + i], pos = h & 0xfffu, n = h >> 12, wi = me.base + i;
+        const uint32_t *hp = hops + (uint64_t)unit * hop_cap;
+        for (uint32_t i = 0; i < me.count; ++i) {
+            const uint32_t h = hp[i], pos = h & 0xfffu, n = h >> 12, wi = me.base + i;
             wave_off[wbase + wi] = at + pos;
             wave_words[wbase + wi] = n;
             // the chunk's last waveform may be shorter than the rest: its header has tighter bounds (the others were held

@@ -58,10 +58,18 @@ def test_direct_path_is_file_compatible_both_ways(env, h5tool, tmp_path, rows, c
         assert np.array_equal(stored, O.encode_chunk(xp[c * crows:(c + 1) * crows], (M, L)))
         tot += stored.nbytes
     assert tot == st["stored_bytes"]
-    # (c) direct read of a direct-written file
+    # (c) direct read of a direct-written file: by preads at the chunk addresses HDF5 reports (the default for a plain
+    # read-only file), and by H5Dread_chunk (any other file; DRX_H5_NO_RAW=1)
     y = torch.empty_like(xd)
     h5io.read(ctx, str(f1), "test", y)
     assert torch.equal(y, xd)
+    os.environ["DRX_H5_NO_RAW"] = "1"
+    try:
+        y.zero_()
+        h5io.read(ctx, str(f1), "test", y)
+        assert torch.equal(y, xd)
+    finally:
+        del os.environ["DRX_H5_NO_RAW"]
     # (d) direct read of a file written chunk by chunk through the filter callback ...
     raw, f2 = tmp_path / "raw.bin", tmp_path / "filter.h5"
     x.tofile(raw)

@@ -110,3 +110,41 @@ def test_one_context_from_four_threads():
     [t.join() for t in ts]
     ctx.close()
     assert not errors, errors[:3]
+
+
+def test_two_contexts_encode_large_batches_at_the_same_time():
+    """Two contexts, two streams, two threads, each encoding batches large enough for the persistent encoder
+    (`k_encode_stream`: its workgroups stay resident, take tickets and wait for a scanner wavefront of their OWN launch) while the
+    other's launch shares the chip: neither may starve the other's scanner or take its tickets, and both streams must be the
+    reference's bytes every time."""
+    import torch
+    import deltarice_amd as dr
+    from oracle import oracle as O
+    rng = np.random.default_rng(11)
+    jobs = []
+    for tid, (n_chunks, W, L) in enumerate([(6, 2000, 3000), (5, 2500, 2500)]):
+        x = rng.normal(0, 10, n_chunks * W * L).astype(np.int16)
+        ref_w, ref_off = O.encode_batch(x, W * L, (8, L))
+        jobs.append((n_chunks, W, L, x, ref_w, ref_off))
+    errors = []
+
+    def worker(tid):
+        try:
+            n_chunks, W, L, x, ref_w, ref_off = jobs[tid]
+            ctx = dr.Context(0)
+            ctx.set_option("debug_flags", 524288)  # the persistent encoder whatever the dispatch would say
+            plan = ctx.plan_uniform(n_chunks, W * L, (8, L))
+            xd = torch.from_numpy(x).to(ctx.device)
+            for it in range(6):
+                enc = plan.encode(xd)
+                w, off = enc.to_numpy()
+                assert np.array_equal(off, ref_off) and np.array_equal(w, ref_w), f"thread {tid} round {it}: encode"
+                assert torch.equal(plan.decode(enc), xd), f"thread {tid} round {it}: decode"
+            ctx.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors[:3]

@@ -131,7 +131,7 @@ enum { kBlkSkip = 0, kBlkCount = 1, kBlkValue = 2 };
     do {                                                                                                     \
         if (tid == 0) {                                                                                      \
             const unsigned long long t_now = __builtin_amdgcn_s_memtime();                                   \
-            atomicAdd(prof + (i), t_now - t_prev);                                                           \
+            s_prof[(i)] += t_now - t_prev;                                                                   \
             t_prev = t_now;                                                                                  \
         }                                                                                                    \
     } while (0)
@@ -351,7 +351,14 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
     constexpr int NQ = (int)((BG::kLdsWords / 4u + NT - 1u) / NT);  // 16-byte pieces of an image per thread
 
 #ifdef DRX_BLK_STAMPS
+    // (per workgroup in LDS, added to the launch's counters once at the end: an atomic per stamp on sixteen shared addresses was
+    // itself what the stamped build waited for)
+    __shared__ unsigned long long s_prof[16];
+    if (tid < 16u) s_prof[tid] = 0ull;
     unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+    auto flush_prof = [&]() { if (tid == 0) for (int i = 0; i < 10; ++i) atomicAdd(prof + i, s_prof[i]); };
+#else
+    auto flush_prof = [] {};
 #endif
     // tickets: every lower ticket is held by a running (or finished) workgroup, so waiting for a predecessor cannot
     // deadlock whatever the dispatch order; the grid is sized to be resident
@@ -868,6 +875,31 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
                 typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
                 const u16x2 b2 = {(uint16_t)base16, (uint16_t)base16};
                 uint16_t *const op = obuf + (a0 + rel0);
+#ifndef DRX_BLK_REORDER16
+                if (!RESID) {
+                    // WHOLE dwords: a lane whose first sample sits in the high half of a dword (odd position) writes that dword
+                    // with the sample in front of its first one in the low half -- which is the running sum in front of it, base16,
+                    // whoever decoded it -- and a lane whose last sample sits in a low half leaves the high half to its successor
+                    // and stores that sample alone, once (both stores carry the same value).  38 four-byte stores per lane instead
+                    // of 76 two-byte ones, at the same three VALU instructions per pair (add, byte permute, compare).
+                    const uint32_t o = a0 + rel0;
+                    const bool odd = (o & 1u) != 0u;
+                    uint32_t *const dp = reinterpret_cast<uint32_t *>(obuf) + (o >> 1);
+                    const uint32_t sel = odd ? 0x05040302u : 0x07060504u;  // odd: (prev.hi, cur.lo); even: cur
+                    const uint32_t lim = cnt == 0u ? 0u : (odd ? cnt : cnt - 1u);  // dword j is written if 2 j < lim
+                    uint32_t prevp = __builtin_bit_cast(uint32_t, b2);
+#pragma unroll
+                    for (int i = 0; i < NR; ++i) {
+                        if (2u * (uint32_t)i < wmax) {
+                            const uint32_t cur = __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, rr[i]) + b2));
+                            const uint32_t d = __builtin_amdgcn_perm(cur, prevp, sel);
+                            if (2u * (uint32_t)i < lim) dp[i] = d;
+                            prevp = cur;
+                        }
+                    }
+                    if (cnt != 0u) op[cnt - 1u] = (uint16_t)(base16 + sum);  // (my last sample = the running sum behind my codes)
+                } else
+#endif
 #pragma unroll
                 for (int i = 0; i < NR; ++i) {
                     if (2u * (uint32_t)i < wmax) {
@@ -903,8 +935,11 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             blk_barrier();  // W, the staging buffer and the s_* words are rewritten by the next block
             BLK_STAMP(8);
+#ifdef DRX_BLK_STAMPS
+            if (tid == 0) s_prof[9] += 1ull;
+#endif
         }
-        if (next_unit >= total_units) return;
+        if (next_unit >= total_units) { flush_prof(); return; }
         unit = next_unit;
         cur = nxt;
     }
@@ -1132,7 +1167,7 @@ hipError_t launch_decode_blocks(const Geom &G, const uint32_t *d_in, uint64_t in
         for (int i = 0; i < 9; ++i) tot += h[i];
         fprintf(stderr, "[blk stamps]");
         for (int i = 0; i < 9; ++i) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)h[i] / (double)(tot ? tot : 1));
-        fprintf(stderr, "\n");
+        fprintf(stderr, "  | %llu blocks, %.0f ticks of s_memtime each\n", h[9], (double)tot / (double)(h[9] ? h[9] : 1));
     }
 #endif
     *fail_out = L.fail;

@@ -434,9 +434,13 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
             if (T == 0) {
                 scan_publish(scan_state, T, kScanPrefix | block_sum, lane);
             } else {
+#ifdef DRX_PC_NOLB
+                excl_words = (uint64_t)T * 12000ull;  // ablation: no look-back (positions wrong, results invalid)
+#else
                 scan_publish(scan_state, T, kScanAgg | block_sum, lane);
                 excl_words = lookback_sum(scan_state, T, 0, lane, st);
                 scan_publish(scan_state, T, kScanPrefix | (excl_words + block_sum), lane);
+#endif
             }
         } else {
             // bits of the waveform in front of this part: look-back over the waveform's parts (workgroups T - part .. T)

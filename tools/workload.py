@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--ramp", action="store_true", help="a slope-1 sawtooth instead of noise (a DAQ's test pattern: codes of one length, "
                     "a speculative parse never falls into step)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--encode-only", action="store_true", help="time the encoder alone (ablation builds whose streams do not decode)")
     ap.add_argument("--debug-flags", type=int, default=0)
     ap.add_argument("--sideband", action="store_true", help="decode with the encoder's n_i table as a side-band (drx_decode_with_wave_words)")
     ap.add_argument("--white", action="store_true", help="_fir4 workloads: white noise as it is (the filter then hurts)")
@@ -138,6 +139,9 @@ def main():
         t = plan.last_timings()
         if i:
             te.append(t)
+        if a.encode_only:
+            td.append([0.0, 0.0, 0.0, 1.0])
+            continue
         if a.sideband:
             table = plan.wave_words_device()
             plan.decode_with_wave_words(words, off, table, y, in_words=nwords)
@@ -147,7 +151,7 @@ def main():
         t = plan.last_timings()
         if i:
             td.append(t)
-    if not a.no_verify:
+    if not a.no_verify and not a.encode_only:
         assert torch.equal(x, y), "round trip failed"
     te, td = np.median(np.array(te), axis=0), np.median(np.array(td), axis=0)
     raw = total * 2

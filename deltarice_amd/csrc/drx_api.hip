@@ -80,6 +80,7 @@ struct drx_plan {
     uint64_t *d_chunk_words = nullptr;
     uint64_t *d_scan = nullptr;        // look-back state of the single-pass encoder + ticket
     uint64_t enc_words_per_wave = 0;   // of the plan's last encode (0: none yet)
+    bool es_segs_ok = false;           // d_scan holds k_encode_stream_segs' state for this geometry (plan_alloc)
     int32_t *d_taps = nullptr;         // general prediction filter (nullptr: delta)
     uint32_t *d_seg_bits = nullptr;    // few long waveforms: bits and bit position of every 8192-sample segment,
     uint64_t *d_seg_pos = nullptr;     // allocated by the first encode that needs them
@@ -308,8 +309,18 @@ static drx_status plan_alloc(drx_ctx *ctx, drx_plan *p) {  // (callers hold the 
     DRX_HIP(ctx, hipMalloc((void **)&p->d_wave_rel, W * sizeof(uint32_t)));
     DRX_HIP(ctx, hipMalloc((void **)&p->d_wave_off, W * sizeof(uint64_t)));
     DRX_HIP(ctx, hipMalloc((void **)&p->d_chunk_words, (p->G.n_chunks + 1) * sizeof(uint64_t)));
-    DRX_HIP(ctx, hipMalloc((void **)&p->d_scan, (2 * W + 192) * sizeof(uint64_t)));  // (k_encode_stream: size[W] | place[W] | control)
-    DRX_HIP(ctx, hipMemset(p->d_scan, 0, (2 * W + 192) * sizeof(uint64_t)));
+    // (k_encode_stream: size[W] | place[W] | control; its segment form: size[T] | place[2 T] | control with T tickets, at most
+    // those of the shortest segments the dispatch may choose)
+    uint64_t scan_words = 2 * W + 192;
+    if (p->G.uniform && p->G.u_wave_len >= 64u) {
+        const uint64_t tickets = W * es_seg_shape(p->G.u_wave_len, kEsSegMinLen).tpw;
+        if (tickets < 0xffff0000ull) {
+            p->es_segs_ok = true;
+            if (3 * tickets + 192 > scan_words) scan_words = 3 * tickets + 192;
+        }
+    }
+    DRX_HIP(ctx, hipMalloc((void **)&p->d_scan, scan_words * sizeof(uint64_t)));
+    DRX_HIP(ctx, hipMemset(p->d_scan, 0, scan_words * sizeof(uint64_t)));
     DRX_HIP(ctx, hipMalloc((void **)&p->d_status, sizeof(DevStatus)));
     DRX_HIP(ctx, hipHostMalloc((void **)&p->h_status, sizeof(DevStatus), hipHostMallocDefault));
     memset(p->h_status, 0, sizeof(DevStatus));
@@ -617,6 +628,29 @@ static bool stream_encoder_suits(const drx_plan *p) {
     return words <= (uint64_t)kEsRingWords * 67u / 100u;
 }
 
+// k_encode_stream_segs or k_encode_pieces?  Long waveforms in a batch that feeds the persistent grid's 4096 wavefronts a few
+// segments each; returns the segment length to aim at (0: not this encoder) -- what leaves a ring room for most of the next
+// segment (57 % of it, as a 7000-sample waveform of the headline does), from the bits per sample of the plan's last encode or,
+// before that, k + 3.5.  Debug flag 4194304: wherever the geometry allows, in segments of kEsSegMinLen samples (tests).
+constexpr uint64_t kEsSegsFromLen = 20480;  // WaveformLengths from here on take the segment form (16 384: k_encode_pieces 0.61 ms, this 0.66; 24 000: 0.69 / 0.61)
+static uint32_t stream_segs_target(const drx_plan *p, uint32_t dbg, int encode_impl) {
+    const Geom &G = p->G;
+    if (encode_impl != 2 || !p->es_segs_ok || !(G.n_taps == 0 || G.enc_fast) || (dbg & 4096u)) return 0u;
+    if (dbg & 4194304u) return kEsSegMinLen;
+    const uint64_t L = G.u_wave_len;
+    uint64_t min_len = kEsSegsFromLen;
+#ifdef DRX_ABLATION
+    if (const char *e = getenv("DRX_SEGS_MIN_LEN")) min_len = (uint64_t)atoll(e);  // (A/B builds: where the two encoders cross)
+#endif
+    if (L < min_len) return 0u;
+    const uint64_t bps16 = p->enc_words_per_wave ? (p->enc_words_per_wave * 512u) / L : 16u * G.k + 56u;  // bits per sample x 16
+    uint64_t t = ((uint64_t)kEsRingWords * 32u * 57u / 100u) * 16u / (bps16 ? bps16 : 1u);
+    t = t > kEsSegMaxLen ? kEsSegMaxLen : (t < kEsSegMinLen ? kEsSegMinLen : t);
+    const EsSegShape sh = es_seg_shape((uint32_t)L, (uint32_t)t);
+    if (G.total_waves * sh.nseg < 8192u) return 0u;
+    return (uint32_t)t;
+}
+
 drx_status drx_encode(drx_plan *p, const int16_t *d_in, uint32_t *d_out, uint64_t out_cap_words,
                       uint64_t *d_chunk_word_off) {
     if (!p || !d_in || !d_out || !d_chunk_word_off) return DRX_ERR_ARG;
@@ -625,7 +659,10 @@ drx_status drx_encode(drx_plan *p, const int16_t *d_in, uint32_t *d_out, uint64_
     DRX_HIP(ctx, hipMemsetAsync(p->d_status, 0, sizeof(DevStatus), ctx->stream));
     p->G.dbg = ctx->debug_flags;
     const bool single = ctx->encode_impl >= 1;
-    if (single && p->d_pc_scan && pieces_batch(p->G)) {
+    if (const uint32_t seg_target = stream_segs_target(p, ctx->debug_flags, ctx->encode_impl)) {
+        DRX_HIP(ctx, launch_encode_stream_segs(p->G, seg_target, d_in, d_out, out_cap_words, d_chunk_word_off, p->d_wave_words,
+                                               p->d_scan, p->d_status, ctx->profile ? p->ev : nullptr, ctx->stream));
+    } else if (single && p->d_pc_scan && pieces_batch(p->G)) {
         DRX_HIP(ctx, launch_encode_pieces(p->G, d_in, p->total_samples, d_out, out_cap_words, d_chunk_word_off, p->d_wave_words,
                                           p->d_pc_scan, p->pc_wgs, p->d_status, ctx->profile ? p->ev : nullptr, ctx->stream));
     } else if (single && long_batch(p->G) && !(ctx->debug_flags & 256u)) {
@@ -661,8 +698,10 @@ static drx_status decode_launch(drx_plan *p, const uint32_t *d_in, uint64_t in_w
     DRX_HIP(ctx, hipMemsetAsync(p->d_status, 0, sizeof(DevStatus), ctx->stream));
     p->G.dbg = ctx->debug_flags;
     // (a stream of this plan's geometry also says how long a waveform's code is: the next encode's kernel is chosen by it,
-    // stream_encoder_suits() -- callers that never wait for an encode, like bench.py's steps, are covered this way)
-    if (p->G.total_waves) p->enc_words_per_wave = in_words / p->G.total_waves;
+    // stream_encoder_suits() -- callers that never wait for an encode, like bench.py's steps, are covered this way
+    // -- in_words may be the buffer's capacity rather than the stream's length: it only ever lowers an estimate)
+    if (p->G.total_waves && (p->enc_words_per_wave == 0 || in_words / p->G.total_waves < p->enc_words_per_wave))
+        p->enc_words_per_wave = in_words / p->G.total_waves;
     if (d_sideband) {  // header positions from the caller's n_i table, checked against the stream (k_sideband_tables)
         DRX_HIP(ctx, launch_sideband_tables(p->G, d_in, in_words, d_chunk_word_off, d_sideband, p->d_wave_off, p->d_wave_words,
                                             p->d_status, ctx->stream));

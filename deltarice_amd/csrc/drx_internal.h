@@ -47,6 +47,7 @@ struct Geom {
                    //  262144 k_encode_stream on three workgroups (tests: every wavefront goes around its ring)
                    //  524288 k_encode_stream (encode_impl 2) whatever the batch (else: where stream_encoder_suits())
                    //  2097152 general filters behind the block decoder: always the separate k_iir_tiles pass
+                   //  4194304 k_encode_stream_segs wherever the batch is uniform, segments of kEsSegMinLen samples
                    // Ablation switches INSIDE the kernels, compiled only with -DDRX_ABLATION (results invalid):
                    //   decode:   1 skip the output stores   2 skip the stream loads
                    //             4 request pieces without counting on the round's minimum consumption   16384 long: no stores
@@ -134,6 +135,37 @@ constexpr uint32_t kEsRingWords = DRX_ES_RING;
 hipError_t launch_encode_stream(const Geom &G, const int16_t *d_in, uint32_t *d_out, uint64_t out_cap,
                                 uint64_t *d_chunk_word_off, uint32_t *d_wave_words, uint64_t *d_scan,
                                 DevStatus *d_status, hipEvent_t *ev, hipStream_t s);
+
+// ... and its form for LONG waveforms (k_encode_stream_segs): the unit a wavefront codes into its ring is a SEGMENT of a
+// waveform, a ticket is kEsSegWaves consecutive segments of ONE waveform, places are bit positions.
+// d_scan: uint64[3 * tickets + 48].  The shape is a function of WaveformLength and the segment length the caller aims at
+// (what a ring holds with room for most of the next segment, from the bits per sample the plan expects).
+constexpr uint32_t kEsSegWaves = 4;
+constexpr uint32_t kEsSegMinLen = 1024, kEsSegMaxLen = 7168;  // samples per segment the host may aim at
+struct EsSegShape { uint32_t seg_len, nseg, tpw; };           // samples per segment (a multiple of 8), segments and tickets per waveform
+__host__ __device__ inline EsSegShape es_seg_shape(uint32_t L, uint32_t seg_target) {
+    EsSegShape sh;
+    uint32_t n = (L + seg_target - 1u) / seg_target;
+    n = n ? n : 1u;
+    // whole tickets: fewer, longer segments or more, shorter ones -- whichever costs less.  Measured on 50 chunks of 14 M samples
+    // (profiles/r04_notes.md section 10): segments 17 % above the target (a ring then holds little of the next one) +9.5 %, 22 %
+    // below it (a ticket's fixed costs per fewer samples) +9 %, 41 % below +16 %; never above 67 / 57 of the target (what
+    // k_encode_stream accepts of a ring, stream_encoder_suits()).
+    const uint32_t dn = n / kEsSegWaves * kEsSegWaves, up = (n + kEsSegWaves - 1u) / kEsSegWaves * kEsSegWaves;
+    n = up;
+    if (dn && dn != up) {
+        const uint64_t sd = (L + dn - 1u) / dn, su = (L + up - 1u) / up;  // (sd > seg_target >= su)
+        const uint64_t pen_dn = sd > seg_target ? (sd - seg_target) * 55u : 0u, pen_up = su < seg_target ? (seg_target - su) * 40u : 0u;
+        if (sd * 57u <= (uint64_t)seg_target * 67u && pen_dn < pen_up) n = dn;
+    }
+    sh.seg_len = (((L + n - 1u) / n) + 7u) & ~7u;                     // equal segments, 16-byte steps
+    sh.nseg = (L + sh.seg_len - 1u) / sh.seg_len;
+    sh.tpw = (sh.nseg + kEsSegWaves - 1u) / kEsSegWaves;
+    return sh;
+}
+hipError_t launch_encode_stream_segs(const Geom &G, uint32_t seg_target, const int16_t *d_in, uint32_t *d_out, uint64_t out_cap,
+                                     uint64_t *d_chunk_word_off, uint32_t *d_wave_words, uint64_t *d_scan,
+                                     DevStatus *d_status, hipEvent_t *ev, hipStream_t s);
 
 // few long waveforms (WaveformLength = -1): a wavefront per 8192-sample segment, see drx_encode_kernels.hip
 bool long_batch(const Geom &G);

@@ -190,7 +190,9 @@ drx_status drx_plan_last_timings(drx_plan *plan, float ms[4]);
  *        waveform is the default, 65536 never the single-pass encoder's larger-buffer geometries (RiceParameter above 8),
  *        262144 the persistent encoder on three workgroups (every wavefront codes many waveforms of a small batch),
  *        524288 the persistent encoder (encode_impl 2) whatever the batch's size and expected code length,
- *        2097152 general filters behind the block decoder: always the separate inverse-filter pass.  (Ablation switches inside the kernels exist only in -DDRX_ABLATION builds.) */
+ *        2097152 general filters behind the block decoder: always the separate inverse-filter pass,
+ *        4194304 the persistent encoder's segment form (long waveforms) wherever the batch is uniform, in segments of ~1024
+ *        samples.  (Ablation switches inside the kernels exist only in -DDRX_ABLATION builds.) */
 drx_status drx_ctx_set_option(drx_ctx *ctx, const char *key, int64_t value);
 
 #ifdef __cplusplus

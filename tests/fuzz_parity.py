@@ -102,7 +102,8 @@ def main():
             xd = dev(ctx, x)
             # (256: no long-waveform paths; 4096: no pieces encoder; 8192: the segment encoder; 32768: the pieces encoder
             # wherever its geometry allows; 65536: the single-pass encoder's standard geometry only)
-            for flags in (0, 256, 4096, 8192, 32768, 65536):
+            # 4194304: the persistent encoder's segment form wherever the batch is uniform (with 262144: on three workgroups)
+            for flags in (0, 256, 4096, 8192, 32768, 65536, 4194304, 4194304 | 262144):
                 for eimpl in ((2, 1, 0) if flags in (0, 256) else (2,)):
                     ctx.set_option("encode_impl", eimpl)
                     # (524288: the persistent encoder whatever the batch's size, where the flags leave the choice to it)

@@ -46,6 +46,9 @@ def gpu_encode(ctx, plan, x):
     ctx.set_option("debug_flags", 256 | 524288)  # (524288: the persistent form whatever the batch's size)
     ws, offs = plan.encode(xd).to_numpy()
     assert np.array_equal(offs, off0) and np.array_equal(ws, w0), "persistent single-pass encoder disagrees"
+    ctx.set_option("debug_flags", 256 | 4194304)  # (its segment form wherever the batch is uniform)
+    wg, offg = plan.encode(xd).to_numpy()
+    assert np.array_equal(offg, off0) and np.array_equal(wg, w0), "segment form of the persistent encoder disagrees"
     ctx.set_option("debug_flags", 32768)
     w2, off2 = plan.encode(xd).to_numpy()
     ctx.set_option("debug_flags", 4096)
@@ -564,11 +567,22 @@ def test_persistent_encoder_rings_and_streaming(ctx, O):
     lens = [512, 2048, 7000, 16384, 0, 3333]
     Ns = [512 * 40, 2048 * 9 + 17, 7000 * 30, 16384 * 4, 4321, 3333 * 21 + 1]
     cases.append(("ragged", Ns, lens, 3, None, noisy(sum(Ns), 10)))
+    # the segment form (k_encode_stream_segs, flag 4194304: segments of ~1024 samples): long waveforms with a shorter last one,
+    # one waveform per chunk, segments that outgrow the ring among ones that do not (the 32 samples coded behind a segment
+    # included), a general filter across segment boundaries, a WaveformLength that is no multiple of anything
+    cases.append(("segs", [100000 * 5 + 777] * 3, [100000] * 3, 3, None, noisy(3 * (100000 * 5 + 777), 10)))
+    cases.append(("segs-whole-chunk", [261001] * 4, [0] * 4, 3, None, noisy(4 * 261001, 25)))
+    x = noisy(40013 * 12, 10)
+    for at in (0, 5000, 40013 * 3 - 40, 40013 * 7 + 1000, 40013 * 12 - 3000):
+        x[at:at + 3000] = rough(3000)
+    cases.append(("segs-streamed-among-ringed", [40013 * 12], [40013], 3, None, x))
+    cases.append(("segs-fir4", [50000 * 6 + 31] * 2, [50000] * 2, 3, (1, -1, 1, -1), noisy(2 * (50000 * 6 + 31), 20)))
+    cases.append(("segs-tiny", [70 * 9 + 5], [70], 3, None, noisy(70 * 9 + 5, 10)))
     for name, Ns, Ls, k, taps, x in cases:
         assert x.size == sum(Ns), name
         uniform = len(set(Ns)) == 1 and len(set(Ls)) == 1
         if uniform:
-            opts = (1 << k, Ls[0]) + ((len(taps),) + tuple(t & 0xFFFFFFFF for t in taps) if taps else ())
+            opts = ((1 << k, Ls[0]) if Ls[0] else (1 << k,)) + ((len(taps),) + tuple(t & 0xFFFFFFFF for t in taps) if taps else ())
             plan = ctx.plan_uniform(len(Ns), Ns[0], opts)
         else:
             plan = ctx.plan(Ns, Ls, 1 << k)
@@ -581,9 +595,9 @@ def test_persistent_encoder_rings_and_streaming(ctx, O):
             at += N
         ref_w, ref_off = np.concatenate(words), np.array(offs, np.uint64)
         xd = dev(ctx, x)
-        for flags in (256 | 4096 | 524288, 256 | 4096 | 524288 | 262144):
+        for flags in (256 | 4096 | 524288, 256 | 4096 | 524288 | 262144, 256 | 4194304, 256 | 4194304 | 262144):
             ctx.set_option("debug_flags", flags)
-            for eimpl in (2, 1):
+            for eimpl in ((2, 1) if flags & 4096 else (2,)):
                 ctx.set_option("encode_impl", eimpl)
                 enc = plan.encode(xd)
                 w, off = enc.to_numpy()

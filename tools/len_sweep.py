@@ -32,9 +32,9 @@ def main():
         torch.cuda.synchronize()  # x was made on torch's default stream, the codec runs on ctx.stream
         te, tw, td, tt = [], [], [], []
         for _ in range(3):
-            plan.encode_async(x, words, off); plan.finish()
+            plan.encode_async(x, words, off); nw = plan.finish()
             te.append(plan.last_timings()[3])
-            plan.decode_async(words, off, y); plan.finish()
+            plan.decode_async(words, off, y, in_words=nw); plan.finish()
             t = plan.last_timings()
             tw.append(t[0]); td.append(t[1]); tt.append(t[3])
         assert os.environ.get("DRX_NO_VERIFY") or torch.equal(x, y)

@@ -60,6 +60,10 @@ def geometry(name):
         return [32 * 81920] * 256, [81920] * 256
     if name == "noptrex":
         return [32 * 500000] * 64, [500000] * 64
+    if name == "nedm_short":  # calibration: the nEDM batch's samples as waveforms of one segment's length (k_encode_stream proper)
+        return [32 * 12 * 6832] * 256, [6832] * 256
+    if name == "noptrex_short":
+        return [32 * 72 * 6952] * 64, [6952] * 64
     if name == "nab100":
         return [2000 * 7000] * 100, [7000] * 100
     if name == "nab1":

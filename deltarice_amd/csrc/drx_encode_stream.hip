@@ -857,6 +857,7 @@ __global__ __launch_bounds__(64 * WV, 4) void k_encode_stream_segs(Geom G, uint3
         return true;
     };
     auto wait_place = [&]() -> EsPlace2 {
+        if (kAblate && (G.dbg & 128u)) return EsPlace2{(uint64_t)TA * WV * 2048ull, 0ull};  // ablation: no waiting at all (positions are wrong)
         uint32_t spins = 0;
         for (;;) {
             EsPlace2 pl;
@@ -1083,6 +1084,7 @@ __global__ __launch_bounds__(64 * WV, 4) void k_encode_stream_segs(Geom G, uint3
         bool polling = false;
         auto between = [&]() {
             if (!pend) return;
+            if (kAblate && (G.dbg & 128u)) { place_to_lds(wait_place()); return; }
             if (polling) {
                 polling = false;
                 EsPlace2 pl;

@@ -459,6 +459,49 @@ def test_full_size_headline_batch(ctx, O):
     assert torch.equal(enc2.words[:enc2.total_words], enc.words[:enc.total_words])
 
 
+@pytest.mark.parametrize("n_chunks,W,L,filt", [(256, 32, 81920, None), (64, 32, 500000, None), (25, 1, 14_000_000, None),
+                                               (64, 32, 500000, (1, -1, 1, -1)), (40, 3, 3_000_017, None)])
+def test_full_size_long_waveform_batches(ctx, O, n_chunks, W, L, filt):
+    """The reference's long-waveform shapes at FULL size (nEDM 256 x 32 x 81 920 and NOPTREX 64 x 32 x 500 000,
+    docs/Performance.md:27,38; 25 chunks of one 14 M-sample waveform, its default options; NOPTREX with the filter it
+    recommends, docs/Optimization.md:21; a WaveformLength that is no multiple of anything) through the encoder their size
+    selects -- the persistent encoder's segment form, k_encode_stream_segs -- and the block decoder: spot chunks against
+    the oracle bit for bit, the framing's checksum, round trip, the encoder of round 3 (encode_impl 1) byte for byte."""
+    free, _ = torch.cuda.mem_get_info(ctx.device)
+    if free < 16 * 2**30:
+        pytest.skip("needs 16 GB of free HBM")
+    N = W * L
+    x = torch.empty(n_chunks * N, dtype=torch.int16, device=ctx.device)
+    g = torch.Generator(device=ctx.device).manual_seed(L)
+    slab = 1 << 27
+    for s0 in range(0, x.numel(), slab):
+        n = min(slab, x.numel() - s0)
+        x[s0:s0 + n] = torch.randn(n, device=ctx.device, generator=g).mul_(10.0).to(torch.int16)
+    torch.cuda.synchronize()
+    opts = (8, L) + ((len(filt),) + tuple(t & 0xFFFFFFFF for t in filt) if filt else ())
+    plan = ctx.plan_uniform(n_chunks, N, opts)
+    ctx.set_option("encode_impl", 2)
+    enc = plan.encode(x)
+    nw = plan.wave_words().reshape(n_chunks, W)
+    off = enc.chunk_word_off.cpu().numpy()
+    assert off[0] == 0 and off[-1] == enc.total_words
+    assert np.array_equal(np.diff(off), 1 + W + nw.sum(axis=1, dtype=np.uint64))
+    for c in sorted({0, n_chunks // 3, n_chunks - 1}):
+        xc = x[c * N:(c + 1) * N].cpu().numpy()
+        assert enc.chunk_bytes(c) == O.encode_chunk(xc, opts).tobytes(), c
+    y = plan.decode(enc)
+    assert torch.equal(x, y)
+    del y
+    ctx.set_option("encode_impl", 1)
+    enc1 = plan.encode(x)
+    ctx.set_option("encode_impl", 2)
+    assert enc1.total_words == enc.total_words
+    assert torch.equal(enc1.words[:enc1.total_words], enc.words[:enc.total_words])
+    enc2 = plan.encode(x)  # (again, now with the measured bits per sample deciding the segment length)
+    assert enc2.total_words == enc.total_words
+    assert torch.equal(enc2.words[:enc2.total_words], enc.words[:enc.total_words])
+
+
 def test_one_huge_chunk_near_the_format_limit(ctx, O):
     """One chunk of 1.5e9 samples (the format allows 2^31 - 1, src/deltaRice.c:389): 32-bit index arithmetic,
     a leftover waveform, 214 286 hops in one header chain.  Round trip, framing, spot waveforms vs the oracle."""

@@ -32,7 +32,15 @@ def main():
         torch.cuda.synchronize()  # x was made on torch's default stream, the codec runs on ctx.stream
         te, tw, td, tt = [], [], [], []
         for _ in range(3):
-            plan.encode_async(x, words, off); nw = plan.finish()
+            plan.encode_async(x, words, off)
+            if os.environ.get("DRX_SWEEP_ENCODE_ONLY"):  # (ablation builds whose streams do not decode)
+                try:
+                    plan.finish()
+                except dr.DeltaRiceError:
+                    pass
+                te.append(plan.last_timings()[3]); tw.append(0.0); td.append(0.0); tt.append(1.0)
+                continue
+            nw = plan.finish()
             te.append(plan.last_timings()[3])
             plan.decode_async(words, off, y, in_words=nw); plan.finish()
             t = plan.last_timings()

@@ -868,6 +868,9 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
                     rr[i] = 0;
                     if (2u * (uint32_t)i < wmax) rr[i] = my_stage[i];
                 }
+#ifndef DRX_BLK_REORDER16
+                if (RESID) s_e[tid] = sum;  // (a lane's last residual: what the next lane puts in front of its first one, below)
+#endif
                 blk_barrier();  // every lane holds its samples: the buffer may now be rewritten in output order
                 const uint32_t base16 = RESID ? 0u : (acc_base + pre_s + incl_s - sum) & 0xffffu;  // the running sum in front of my first sample
                 // both halves of a dword take the base in one packed add; the two 16-bit stores have immediate offsets from one
@@ -876,18 +879,19 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
                 const u16x2 b2 = {(uint16_t)base16, (uint16_t)base16};
                 uint16_t *const op = obuf + (a0 + rel0);
 #ifndef DRX_BLK_REORDER16
-                if (!RESID) {
+                {
                     // WHOLE dwords: a lane whose first sample sits in the high half of a dword (odd position) writes that dword
                     // with the sample in front of its first one in the low half -- which is the running sum in front of it, base16,
-                    // whoever decoded it -- and a lane whose last sample sits in a low half leaves the high half to its successor
-                    // and stores that sample alone, once (both stores carry the same value).  38 four-byte stores per lane instead
-                    // of 76 two-byte ones, at the same three VALU instructions per pair (add, byte permute, compare).
+                    // whoever decoded it (residual mode: the lane in front's last residual, through s_e) -- and a lane whose last
+                    // sample sits in a low half leaves the high half to its successor and stores that sample alone, once (both
+                    // stores carry the same value).  38 four-byte stores per lane instead of 76 two-byte ones, at the same three
+                    // VALU instructions per pair (add, byte permute, compare).
                     const uint32_t o = a0 + rel0;
                     const bool odd = (o & 1u) != 0u;
                     uint32_t *const dp = reinterpret_cast<uint32_t *>(obuf) + (o >> 1);
                     const uint32_t sel = odd ? 0x05040302u : 0x07060504u;  // odd: (prev.hi, cur.lo); even: cur
                     const uint32_t lim = cnt == 0u ? 0u : (odd ? cnt : cnt - 1u);  // dword j is written if 2 j < lim
-                    uint32_t prevp = __builtin_bit_cast(uint32_t, b2);
+                    uint32_t prevp = RESID ? (tid ? s_e[tid - 1u] << 16 : 0u) : __builtin_bit_cast(uint32_t, b2);
 #pragma unroll
                     for (int i = 0; i < NR; ++i) {
                         if (2u * (uint32_t)i < wmax) {
@@ -897,9 +901,9 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
                             prevp = cur;
                         }
                     }
-                    if (cnt != 0u) op[cnt - 1u] = (uint16_t)(base16 + sum);  // (my last sample = the running sum behind my codes)
-                } else
-#endif
+                    if (cnt != 0u) op[cnt - 1u] = (uint16_t)(base16 + sum);  // (my last sample = the running sum behind my codes; residual mode: my last residual)
+                }
+#else
 #pragma unroll
                 for (int i = 0; i < NR; ++i) {
                     if (2u * (uint32_t)i < wmax) {
@@ -908,6 +912,7 @@ __global__ __launch_bounds__(NT) void k_decode_blocks(Geom G, const uint32_t *__
                         if (2u * (uint32_t)i + 1u < cnt) op[2 * i + 1] = v.y;
                     }
                 }
+#endif
                 blk_barrier();
                 BLK_STAMP(6);  // reorder
                 if (FUSE) iir_lds(a0, blk_count);

@@ -245,24 +245,29 @@ template <bool RESID>
 __device__ __forceinline__ void blk_count_pairs(const uint32_t *W, uint32_t k, bool enable, uint32_t &Qp, uint32_t qlim,
                                                 uint32_t &c, uint32_t &sum, uint32_t *stage, uint32_t cap2) {
     uint32_t slot = 0, Qa_l = Qp, s1_l = sum;  // (c = 0 on entry)
-    bool act = enable && Qp > qlim;
-    while (__builtin_amdgcn_ballot_w64(act) != 0ull) {
+    // A lane that is not enabled gets a limit no position exceeds: the loop's condition is then ONE compare that is the exec
+    // mask.  The loop is ROTATED (test at the bottom): with the test at the top the compiler kept the values used behind the
+    // loop apart from the loop-carried ones and copied five registers there and back per trip (ten v_mov per four codes, a
+    // seventh of the parse's VALU instructions).
+    const uint32_t ql = enable ? qlim : 0xffffffffu;
+    if (__builtin_amdgcn_ballot_w64(Qp > ql) != 0ull) {
+        do {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {  // one vote per four codes
-            if (act) {
-                const BlkPair p = blk_pair<true>(W, k, Qp);
-                const uint32_t s1 = RESID ? unzigzag(p.z1) : sum + unzigzag(p.z1);
-                const uint32_t s2 = RESID ? unzigzag(p.z2) : s1 + unzigzag(p.z2);
-                stage[slot] = __builtin_amdgcn_perm(s2, s1, 0x05040100u);
-                Qa_l = Qp + p.nu1;
-                s1_l = s1;
-                sum = s2;
-                c += 2u;
-                Qp = Qa_l + p.nu2;
+            for (int u = 0; u < 2; ++u) {  // one vote per four codes
+                if (Qp > ql) {
+                    const BlkPair p = blk_pair<true>(W, k, Qp);
+                    const uint32_t s1 = RESID ? unzigzag(p.z1) : sum + unzigzag(p.z1);
+                    const uint32_t s2 = RESID ? unzigzag(p.z2) : s1 + unzigzag(p.z2);
+                    stage[slot] = __builtin_amdgcn_perm(s2, s1, 0x05040100u);
+                    Qa_l = Qp + p.nu1;
+                    s1_l = s1;
+                    sum = s2;
+                    c += 2u;
+                    Qp = Qa_l + p.nu2;
+                }
+                slot = slot + 1u < cap2 ? slot + 1u : cap2;
             }
-            slot = slot + 1u < cap2 ? slot + 1u : cap2;
-            act = act && Qp > qlim;
-        }
+        } while (__builtin_amdgcn_ballot_w64(Qp > ql) != 0ull);
     }
     if (enable && c != 0u && !(Qa_l > qlim)) { c -= 1u; Qp = Qa_l; sum = s1_l; }
 }
@@ -270,17 +275,18 @@ __device__ __forceinline__ void blk_count_pairs(const uint32_t *W, uint32_t k, b
 // The run-up in the same form: codes are skipped, a pair at a time, while they start in front of the limit.
 __device__ __forceinline__ void blk_skip_pairs(const uint32_t *W, uint32_t k, bool enable, uint32_t &Qp, uint32_t qlim) {
     uint32_t Qa_l = Qp;
-    bool act = enable && Qp > qlim;
-    while (__builtin_amdgcn_ballot_w64(act) != 0ull) {
+    const uint32_t ql = enable ? qlim : 0xffffffffu;  // (as in blk_count_pairs: one compare, a rotated loop)
+    if (__builtin_amdgcn_ballot_w64(Qp > ql) != 0ull) {
+        do {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (act) {
-                const BlkPair p = blk_pair<false>(W, k, Qp);
-                Qa_l = Qp + p.nu1;
-                Qp = Qa_l + p.nu2;
+            for (int u = 0; u < 2; ++u) {
+                if (Qp > ql) {
+                    const BlkPair p = blk_pair<false>(W, k, Qp);
+                    Qa_l = Qp + p.nu1;
+                    Qp = Qa_l + p.nu2;
+                }
             }
-            act = act && Qp > qlim;
-        }
+        } while (__builtin_amdgcn_ballot_w64(Qp > ql) != 0ull);
     }
     if (enable && !(Qa_l > qlim)) Qp = Qa_l;  // (no pair taken: Qa_l is Qp)
 }

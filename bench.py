@@ -349,7 +349,9 @@ def main():
     # passes (collect_traffic(), before the GPU was touched) -- or, where rocprofv3 is missing or a pass failed, read from the
     # newest committed passes of the same command, flagged stale when the kernel sources have changed since
     traffic = traffic_enc = traffic_source = None
-    enc_kernel = "k_encode_stream"  # (encode_impl 2, the default since round 4; encode_impl 1 = k_encode_fused)
+    # the encoder that RAN in the steps above (the dispatch goes by what the plan's last encode measured)
+    enc_kernel = {1: "k_encode_pack", 2: "k_seg_pack", 3: "k_encode_fused", 4: "k_encode_pieces", 5: "k_encode_stream",
+                  6: "k_encode_stream_segs"}.get(plan.last_encode_path(), "?")
     if traffic_kernels is not None:
         traffic = traffic_kernels.get("k_decode_lanes", {}).get("hbm_bytes")
         traffic_enc = (traffic_kernels.get(enc_kernel) or traffic_kernels.get("k_encode_fused", {})).get("hbm_bytes")

@@ -53,6 +53,7 @@ SIGNATURES = {
     "drx_plan_wave_words": (_vp, [_vp]),
     "drx_plan_wave_word_off": (_vp, [_vp]),
     "drx_plan_last_decode_path": (C.c_uint32, [_vp]),
+    "drx_plan_last_encode_path": (C.c_uint32, [_vp]),
     "drx_plan_read_wave_words": (C.c_int, [_vp, C.POINTER(_u32)]),
     "drx_encode": (C.c_int, [_vp, _vp, _vp, _u64, _vp]),
     "drx_decode": (C.c_int, [_vp, _vp, _u64, _vp, _vp]),

@@ -242,6 +242,10 @@ class Plan:
         """DRX_PATH_* bits (include/deltarice_hip.h) of the decoders the last decode used."""
         return int(self.ctx.lib.drx_plan_last_decode_path(self._h))
 
+    def last_encode_path(self) -> int:
+        """DRX_ENC_* (include/deltarice_hip.h): the encoder the last encode used."""
+        return int(self.ctx.lib.drx_plan_last_encode_path(self._h))
+
     def wave_words(self) -> np.ndarray:
         """n_i (payload words) of every waveform from the last encode/decode, on the host."""
         buf = np.empty(self.total_waves, dtype=np.uint32)

@@ -79,6 +79,7 @@ struct drx_plan {
     uint64_t *d_wave_off = nullptr;    // decode: absolute header position
     uint64_t *d_chunk_words = nullptr;
     uint64_t *d_scan = nullptr;        // look-back state of the single-pass encoder + ticket
+    uint32_t last_enc_path = 0;         // DRX_ENC_* of the last drx_encode
     uint64_t enc_words_per_wave = 0;   // of the plan's last encode (0: none yet)
     bool es_segs_ok = false;           // d_scan holds k_encode_stream_segs' state for this geometry (plan_alloc)
     int32_t *d_taps = nullptr;         // general prediction filter (nullptr: delta)
@@ -99,6 +100,7 @@ struct drx_plan {
     uint32_t n_short = 0, n_long = 0;
     DevStatus *d_status = nullptr;
     DevStatus *h_status = nullptr;  // pinned
+    uint64_t *h_enc_words = nullptr;  // pinned, written by the encoders themselves (Geom::host_words): the last encode's word count, 0 = none yet
     bool last_was_encode = false;
     uint32_t last_path = 0;  // DRX_PATH_* of the last decode
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -299,6 +301,7 @@ static void plan_free(drx_plan *p) {
     if (p->d_blk) (void)hipFree(p->d_blk);
     if (p->d_status) (void)hipFree(p->d_status);
     if (p->h_status) (void)hipHostFree(p->h_status);
+    if (p->h_enc_words) (void)hipHostFree(p->h_enc_words);
     for (hipEvent_t e : p->ev) if (e) (void)hipEventDestroy(e);
     delete p;
 }
@@ -324,6 +327,9 @@ static drx_status plan_alloc(drx_ctx *ctx, drx_plan *p) {  // (callers hold the 
     DRX_HIP(ctx, hipMalloc((void **)&p->d_status, sizeof(DevStatus)));
     DRX_HIP(ctx, hipHostMalloc((void **)&p->h_status, sizeof(DevStatus), hipHostMallocDefault));
     memset(p->h_status, 0, sizeof(DevStatus));
+    DRX_HIP(ctx, hipHostMalloc((void **)&p->h_enc_words, sizeof(uint64_t), hipHostMallocDefault));
+    *p->h_enc_words = 0;
+    p->G.host_words = p->h_enc_words;  // (pinned host memory is device-visible at the same address)
     for (hipEvent_t &e : p->ev) DRX_HIP(ctx, hipEventCreate(&e));
     return DRX_OK;
 }
@@ -557,6 +563,8 @@ drx_status drx_plan_set_filter(drx_plan *p, uint32_t n_taps, const int32_t *taps
     if (taps[0] == 0) return fail(ctx, DRX_ERR_ARG, "taps[0] must not be 0 (the inverse filter divides by it)");
     DRX_ON_DEVICE(ctx);
     DRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    p->enc_words_per_wave = 0;  // (another filter, another code length: what the last encode measured no longer applies)
+    if (p->h_enc_words) *p->h_enc_words = 0;
     p->G.fast_taps = 0;
     p->G.enc_fast = 0;
     if (n_taps == 2 && taps[0] == 1 && taps[1] == -1) {  // checkIfDeltaFilter, src/deltaRice.c:38-46
@@ -602,6 +610,7 @@ uint64_t drx_plan_max_encoded_words(const drx_plan *p) { return p ? p->max_words
 const uint32_t *drx_plan_wave_words(const drx_plan *p) { return p ? p->d_wave_words : nullptr; }
 const uint64_t *drx_plan_wave_word_off(const drx_plan *p) { return p ? p->d_wave_off : nullptr; }
 uint32_t drx_plan_last_decode_path(const drx_plan *p) { return p ? p->last_path : 0u; }
+uint32_t drx_plan_last_encode_path(const drx_plan *p) { return p ? p->last_enc_path : 0u; }
 
 drx_status drx_plan_read_wave_words(drx_plan *p, uint32_t *host_out) {
     if (!p || !host_out) return DRX_ERR_ARG;
@@ -658,13 +667,18 @@ drx_status drx_encode(drx_plan *p, const int16_t *d_in, uint32_t *d_out, uint64_
     DRX_ON_DEVICE(ctx);
     DRX_HIP(ctx, hipMemsetAsync(p->d_status, 0, sizeof(DevStatus), ctx->stream));
     p->G.dbg = ctx->debug_flags;
+    // what the plan's last encode measured decides this one's kernel -- read from the word the encoders write to pinned host
+    // memory, so that callers that never wait for an encode (bench.py's steps) are covered without a copy or an event
+    if (const uint64_t w = *(volatile uint64_t *)p->h_enc_words) p->enc_words_per_wave = p->G.total_waves ? w / p->G.total_waves : 0;
     const bool single = ctx->encode_impl >= 1;
     if (const uint32_t seg_target = stream_segs_target(p, ctx->debug_flags, ctx->encode_impl)) {
         DRX_HIP(ctx, launch_encode_stream_segs(p->G, seg_target, d_in, d_out, out_cap_words, d_chunk_word_off, p->d_wave_words,
                                                p->d_scan, p->d_status, ctx->profile ? p->ev : nullptr, ctx->stream));
+        p->last_enc_path = DRX_ENC_STREAM_SEGS;
     } else if (single && p->d_pc_scan && pieces_batch(p->G)) {
         DRX_HIP(ctx, launch_encode_pieces(p->G, d_in, p->total_samples, d_out, out_cap_words, d_chunk_word_off, p->d_wave_words,
                                           p->d_pc_scan, p->pc_wgs, p->d_status, ctx->profile ? p->ev : nullptr, ctx->stream));
+        p->last_enc_path = DRX_ENC_PIECES;
     } else if (single && long_batch(p->G) && !(ctx->debug_flags & 256u)) {
         if (!p->d_seg_bits) {  // only when a diagnostic debug_flags value forces this path on a geometry that does not take it
             const uint64_t units = long_batch_units(p->G);
@@ -674,16 +688,21 @@ drx_status drx_encode(drx_plan *p, const int16_t *d_in, uint32_t *d_out, uint64_
         DRX_HIP(ctx, launch_encode_long(p->G, d_in, d_out, out_cap_words, d_chunk_word_off, p->d_wave_words, p->d_wave_rel,
                                         p->d_chunk_words, p->d_seg_bits, p->d_seg_pos, p->d_status,
                                         ctx->profile ? p->ev : nullptr, ctx->stream));
-    } else if (ctx->encode_impl == 2 && (p->G.n_taps == 0 || p->G.enc_fast) && (stream_encoder_suits(p) || (ctx->debug_flags & 524288u)))
+        p->last_enc_path = DRX_ENC_SEGMENTS;
+    } else if (ctx->encode_impl == 2 && (p->G.n_taps == 0 || p->G.enc_fast) && (stream_encoder_suits(p) || (ctx->debug_flags & 524288u))) {
         DRX_HIP(ctx, launch_encode_stream(p->G, d_in, d_out, out_cap_words, d_chunk_word_off, p->d_wave_words,
                                           p->d_scan, p->d_status, ctx->profile ? p->ev : nullptr, ctx->stream));
-    else if (single && (p->G.n_taps == 0 || p->G.enc_fast))
+        p->last_enc_path = DRX_ENC_STREAM;
+    } else if (single && (p->G.n_taps == 0 || p->G.enc_fast)) {
         DRX_HIP(ctx, launch_encode_fused(p->G, d_in, d_out, out_cap_words, d_chunk_word_off, p->d_wave_words,
                                          p->d_scan, p->d_status, ctx->profile ? p->ev : nullptr, ctx->stream));
-    else
+        p->last_enc_path = DRX_ENC_FUSED;
+    } else {
         DRX_HIP(ctx, launch_encode(p->G, d_in, d_out, out_cap_words, d_chunk_word_off, p->d_wave_words,
                                    p->d_wave_rel, p->d_chunk_words, p->d_status, ctx->profile ? p->ev : nullptr,
                                    ctx->stream));
+        p->last_enc_path = DRX_ENC_TWO_PASS;
+    }
     p->ev_valid = ctx->profile != 0;
     p->last_was_encode = true;
     return DRX_OK;
@@ -697,11 +716,8 @@ static drx_status decode_launch(drx_plan *p, const uint32_t *d_in, uint64_t in_w
     DRX_ON_DEVICE(ctx);
     DRX_HIP(ctx, hipMemsetAsync(p->d_status, 0, sizeof(DevStatus), ctx->stream));
     p->G.dbg = ctx->debug_flags;
-    // (a stream of this plan's geometry also says how long a waveform's code is: the next encode's kernel is chosen by it,
-    // stream_encoder_suits() -- callers that never wait for an encode, like bench.py's steps, are covered this way
-    // -- in_words may be the buffer's capacity rather than the stream's length: it only ever lowers an estimate)
-    if (p->G.total_waves && (p->enc_words_per_wave == 0 || in_words / p->G.total_waves < p->enc_words_per_wave))
-        p->enc_words_per_wave = in_words / p->G.total_waves;
+    // (in_words says nothing about how long a waveform's code is -- it may be, and in bench.py IS, the buffer's capacity; round 4
+    // took it for the stream's length for a while and sent the headline batch to k_encode_fused)
     if (d_sideband) {  // header positions from the caller's n_i table, checked against the stream (k_sideband_tables)
         DRX_HIP(ctx, launch_sideband_tables(p->G, d_in, in_words, d_chunk_word_off, d_sideband, p->d_wave_off, p->d_wave_words,
                                             p->d_status, ctx->stream));

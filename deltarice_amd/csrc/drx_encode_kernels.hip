@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void k_chunk_scan(Geom G, const uint32_t *__re
 // Exclusive prefix over chunk totals -> chunk_word_off[0..n_chunks]; one workgroup.
 __global__ __launch_bounds__(1024) void k_chunk_offsets(uint64_t n_chunks, const uint64_t *__restrict__ chunk_words,
                                                         uint64_t *__restrict__ chunk_word_off,
-                                                        uint64_t out_cap, DevStatus *st) {
+                                                        uint64_t out_cap, DevStatus *st, uint64_t *host_words) {
     __shared__ uint64_t wsum[16];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     uint64_t run = 0;
@@ -199,6 +199,7 @@ __global__ __launch_bounds__(1024) void k_chunk_offsets(uint64_t n_chunks, const
     if (threadIdx.x == 0) {
         chunk_word_off[n_chunks] = run;
         st->total_words = run;
+        if (host_words) *host_words = run;  // (Geom::host_words)
         if (run > out_cap) atomicOr(&st->err, kErrCapacity);
     }
 }
@@ -579,6 +580,7 @@ __global__ __launch_bounds__(64 * WV, DRX_ENC_WAVES_PER_EU) void k_encode_fused(
         if (g + 1 == G.total_waves) {
             chunk_word_off[G.n_chunks] = excl + mine;
             st->total_words = excl + mine;
+            if (G.host_words) *G.host_words = excl + mine;
             if (excl + mine > out_cap) atomicOr(&st->err, kErrCapacity);
         }
     }
@@ -926,7 +928,7 @@ hipError_t launch_encode(const Geom &G, const int16_t *d_in, uint32_t *d_out, ui
     k_encode_sizes<<<blocks_for(G.total_waves, 4), 256, 0, s>>>(G, d_in, d_wave_words);
     mark(ev, 1, s);
     k_chunk_scan<<<(unsigned)G.n_chunks, 256, 0, s>>>(G, d_wave_words, d_wave_rel, d_chunk_words);
-    k_chunk_offsets<<<1, 1024, 0, s>>>(G.n_chunks, d_chunk_words, d_chunk_word_off, out_cap, d_status);
+    k_chunk_offsets<<<1, 1024, 0, s>>>(G.n_chunks, d_chunk_words, d_chunk_word_off, out_cap, d_status, G.host_words);
     mark(ev, 2, s);
     k_encode_pack<<<blocks_for(G.total_waves, 4), 256, 0, s>>>(G, d_in, d_wave_words, d_wave_rel,
                                                                d_chunk_word_off, d_out, out_cap);
@@ -965,7 +967,7 @@ hipError_t launch_encode_long(const Geom &G, const int16_t *d_in, uint32_t *d_ou
     mark(ev, 1, s);
     k_seg_scan<<<(unsigned)G.total_waves, 64, 0, s>>>(G, S, d_seg_bits, d_seg_pos, d_wave_words);
     k_chunk_scan<<<(unsigned)G.n_chunks, 256, 0, s>>>(G, d_wave_words, d_wave_rel, d_chunk_words);
-    k_chunk_offsets<<<1, 1024, 0, s>>>(G.n_chunks, d_chunk_words, d_chunk_word_off, out_cap, d_status);
+    k_chunk_offsets<<<1, 1024, 0, s>>>(G.n_chunks, d_chunk_words, d_chunk_word_off, out_cap, d_status, G.host_words);
     k_seg_zero<<<blocks_for(units, 256), 256, 0, s>>>(G, S, units, d_seg_pos, d_wave_rel, d_chunk_word_off, d_out, out_cap);
     mark(ev, 2, s);
     k_seg_pack<<<blocks_for(units, 4 * upw), 256, 0, s>>>(G, d_in, S, units, d_seg_pos, d_wave_words, d_wave_rel, d_chunk_word_off,

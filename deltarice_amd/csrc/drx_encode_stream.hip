@@ -248,6 +248,7 @@ __global__ __launch_bounds__(64 * WV, 4) void k_encode_stream(Geom G, const int1
             if (g + 1 == G.total_waves) {
                 chunk_word_off[G.n_chunks] = ex + mine;
                 st->total_words = ex + mine;
+                if (G.host_words) *G.host_words = ex + mine;
                 if (ex + mine > out_cap) atomicOr(&st->err, kErrCapacity);
             }
         }
@@ -775,6 +776,7 @@ __global__ __launch_bounds__(64 * WV, 4) void k_encode_stream_segs(Geom G, uint3
                 const uint64_t tot = pl.whdr + 1ull + n;
                 chunk_word_off[G.n_chunks] = tot;
                 st->total_words = tot;
+                if (G.host_words) *G.host_words = tot;
                 if (tot > out_cap) atomicOr(&st->err, kErrCapacity);
             }
         }

@@ -38,6 +38,9 @@ struct Geom {
     uint32_t enc_fast;
     uint32_t enc_t[4];
     uint64_t total_samples;  // of the batch
+    // pinned host word (device-visible) that every encoder writes the batch's encoded word count to beside DevStatus: the host
+    // reads it -- without waiting for anything -- when it chooses the NEXT encode's kernel (drx_api.hip, stream_encoder_suits())
+    uint64_t *host_words;
     uint32_t dbg;  // "debug_flags" context option; 0 in normal use.  Dispatch overrides (host side, always available, every
                    // forced path is bit-exact and the tests use them to reach it):
                    //   256 never take the long-waveform paths   512 long waveforms: one workgroup per waveform only

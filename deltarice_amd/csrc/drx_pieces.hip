@@ -478,6 +478,7 @@ __global__ __launch_bounds__(64 * kPcWaves) void k_encode_pieces(Geom G, const i
             if (T + 1u == total_wgs) {  // (SUPER: the last part of the last waveform)
                 chunk_word_off[G.n_chunks] = excl_words + sum_words;
                 st->total_words = excl_words + sum_words;
+                if (G.host_words) *G.host_words = excl_words + sum_words;
                 if (excl_words + sum_words > out_cap) atomicOr(&st->err, kErrCapacity);
             }
         }

@@ -156,6 +156,15 @@ const uint64_t *drx_plan_wave_word_off(const drx_plan *plan);
 #define DRX_PATH_IIR 32u        /* residuals first, then the general filter's inverse in place, parallel inside a waveform */
 #define DRX_PATH_IIR_FUSED 64u  /* the general filter's inverse inside the block decoder: one kernel, samples straight to the output */
 uint32_t drx_plan_last_decode_path(const drx_plan *plan);
+/* ... and which encoder its last drx_encode used (one value; bench.py names the kernel it prices by this, and the tests
+ * hold the dispatch to it: the headline batch must take DRX_ENC_STREAM whatever in_words its decodes were given) */
+#define DRX_ENC_TWO_PASS 1u    /* sizes, scan, pack (encode_impl 0; more than four taps) */
+#define DRX_ENC_SEGMENTS 2u    /* the two-pass segment encoder (the geometries only it serves) */
+#define DRX_ENC_FUSED 3u       /* k_encode_fused: a wavefront per waveform, one pass */
+#define DRX_ENC_PIECES 4u      /* k_encode_pieces: runs of short waveforms / segments of long ones */
+#define DRX_ENC_STREAM 5u      /* k_encode_stream: persistent, a ring per wavefront, a scanner */
+#define DRX_ENC_STREAM_SEGS 6u /* k_encode_stream_segs: the same over segments of long waveforms */
+uint32_t drx_plan_last_encode_path(const drx_plan *plan);
 /* Copies n_i of every waveform to host memory (waits for the stream). */
 drx_status drx_plan_read_wave_words(drx_plan *plan, uint32_t *host_out);
 

@@ -660,6 +660,46 @@ def test_persistent_encoder_rings_and_streaming(ctx, O):
     ctx.set_option("encode_impl", 2)
 
 
+def test_encoder_dispatch_follows_the_measured_code_length(ctx, O):
+    """Which encoder a batch gets (drx_plan_last_encode_path).  The persistent encoder where a waveform's code leaves a ring
+    room for the next -- by what the plan's last encode MEASURED, read from the word the encoders write to pinned host memory,
+    so also for callers that never wait for an encode and hand the decoder the buffer's capacity as in_words (bench.py does:
+    for a while that capacity was taken for the stream's length, and the headline batch went to k_encode_fused); the
+    single pass with a look-back per workgroup where the code is long; the segment form for long waveforms."""
+    ENC_FUSED, ENC_PIECES, ENC_STREAM, ENC_SEGS = 3, 4, 5, 6
+    rng = np.random.default_rng(77)
+    W, L, n_chunks = 2100, 7000, 4  # 8400 waveforms: enough for the persistent grid
+    for sigma, k, want in ((10, 3, ENC_STREAM), (400, 3, ENC_FUSED)):  # (sigma 400 under m = 8: ~16 bits per sample, 3500 words)
+        x = rng.normal(0, sigma, n_chunks * W * L).astype(np.int16)
+        xd = dev(ctx, x)
+        plan = ctx.plan_uniform(n_chunks, W * L, (1 << k, L))
+        words = torch.empty(plan.max_encoded_words, dtype=torch.int32, device=ctx.device)
+        off = torch.empty(n_chunks + 1, dtype=torch.int64, device=ctx.device)
+        y = torch.empty_like(xd)
+        for _ in range(3):  # bench.py's step: no finish() between, in_words = the buffer's capacity
+            plan.encode_async(xd, words, off)
+            plan.decode_async(words, off, y)
+        ctx.stream.synchronize()
+        plan.encode_async(xd, words, off)
+        assert plan.last_encode_path() == want, (sigma, plan.last_encode_path())
+        n = plan.finish()
+        ref_w, ref_off = O.encode_batch(x, W * L, (1 << k, L))
+        assert n == ref_w.size and np.array_equal(words[:n].cpu().numpy().view(np.uint32), ref_w)
+        assert torch.equal(y, xd)
+    # long waveforms: the segment form once the batch has 8192 segments, k_encode_pieces below that and with encode_impl 1
+    for n_chunks, want in ((2, ENC_PIECES), (40, ENC_SEGS)):
+        x = rng.normal(0, 10, n_chunks * 32 * 50000).astype(np.int16)
+        plan = ctx.plan_uniform(n_chunks, 32 * 50000, (8, 50000))
+        enc = plan.encode(dev(ctx, x))
+        assert plan.last_encode_path() == want, (n_chunks, plan.last_encode_path())
+        if n_chunks == 2:
+            assert enc.chunk_bytes(1) == O.encode_chunk(x[32 * 50000:], (8, 50000)).tobytes()
+    ctx.set_option("encode_impl", 1)
+    plan.encode(dev(ctx, x))
+    assert plan.last_encode_path() == ENC_PIECES
+    ctx.set_option("encode_impl", 2)
+
+
 def test_rice_parameter_optimiser_is_exact(ctx, O):
     rng = np.random.default_rng(31)
     x = (rng.standard_t(3, 4 * 6000) * 25).clip(-32768, 32767).astype(np.int16)

@@ -698,6 +698,17 @@ def test_encoder_dispatch_follows_the_measured_code_length(ctx, O):
     plan.encode(dev(ctx, x))
     assert plan.last_encode_path() == ENC_PIECES
     ctx.set_option("encode_impl", 2)
+    # one plan, data of another noise level every time: segments sized for quiet data (7000 samples) meet ~17 bits per sample
+    # (every segment outgrows its ring and is coded again to its place), then the measured length shortens them (~2700
+    # samples), then quiet data again in those short segments -- the oracle's bytes every time
+    N = 32 * 50000
+    for i, sigma in enumerate((10, 3000, 3000, 2, 2)):
+        x = rng.normal(0, sigma, 40 * N).astype(np.int16)
+        enc = plan.encode(dev(ctx, x))
+        assert plan.last_encode_path() == ENC_SEGS, (i, sigma)
+        for c in (0, 17, 39):
+            assert enc.chunk_bytes(c) == O.encode_chunk(x[c * N:(c + 1) * N], (8, 50000)).tobytes(), (i, sigma, c)
+        assert np.array_equal(plan.decode(enc).cpu().numpy(), x), (i, sigma)
 
 
 def test_rice_parameter_optimiser_is_exact(ctx, O):

@@ -3,7 +3,8 @@
 Layout: ``csrc/`` holds the HIP kernels, the C ABI and the H5Z plugin source;
 ``codec`` is the host-side batch API over device-resident chunks; ``h5`` mirrors
 the reference's ``deltaRice.h5`` registration module; ``dist`` shards a batch of
-chunks over the GPUs of a node.  There is no CPU implementation in this package.
+chunks over the GPUs of a node; ``optimise`` searches RiceParameter and encoding filter
+(docs/Optimization.md of the reference).  There is no CPU implementation in this package.
 """
 from ._lib import DeltaRiceError, LIB_PATH, PLUGIN_PATH  # noqa: F401
 

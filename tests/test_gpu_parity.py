@@ -723,6 +723,55 @@ def test_rice_parameter_optimiser_is_exact(ctx, O):
     assert est[best] <= est[3]
 
 
+def test_filter_and_rice_parameter_optimiser(ctx, O):
+    """deltarice_amd.optimise: the neighbourhood search over integer filters of docs/Optimization.md:17-19, M in tandem.  Every
+    size it computes is the oracle's encoded size for that filter and RiceParameter; the filter it ends on is a local minimum
+    of its (2s+1)^n neighbourhood; on data made for [1,-1,1,-1] it finds that filter from a neighbour of it."""
+    from deltarice_amd.optimise import optimise
+    rng = np.random.default_rng(17)
+    L, W, n_chunks = 3000, 6, 2
+    N = W * L
+    # (a) a random walk: delta is (near) optimal among two-tap filters
+    x = np.cumsum(rng.normal(0, 12, n_chunks * N)).astype(np.int64)
+    x = ((x + 32768) % 65536 - 32768).astype(np.int16)
+    r = optimise(ctx, dev(ctx, x), N, L, taps=(1, -2), search=1)
+    assert r["taps"] == (1, -1), r["taps"]
+    for f, words in r["evaluated"].items():
+        for k in (0, r["k"], 9):
+            opts = (1 << k, L, len(f)) + tuple(t & 0xFFFFFFFF for t in f)
+            assert int(words[k]) == O.encode_batch(x, N, opts)[0].size, (f, k)
+    best = min(int(w[k]) for w in r["evaluated"].values() for k in range(16))
+    assert r["words"] == best  # (nothing it saw is smaller than what it returned)
+    for d0 in (-1, 0, 1):  # ... and no valid neighbour of the result was left out
+        for d1 in (-1, 0, 1):
+            f = (1 + d0, -1 + d1)
+            if abs(f[0]) == 1 and f[1] != 0:
+                assert f in r["evaluated"], f
+    # (b) data whose residuals under [1,-1,1,-1] are small noise: found from a neighbouring filter, with the m that suits
+    taps = (1, -1, 1, -1)
+    e = rng.normal(0, 6, n_chunks * N).astype(np.int64)
+    y = np.zeros(n_chunks * N, np.int64)
+    for c in range(n_chunks * W):  # per waveform: y[i] = e[i] + y[i-1] - y[i-2] + y[i-3]  (mod 2^16)
+        s = c * L
+        for i in range(L):
+            acc = e[s + i]
+            if i >= 1: acc += y[s + i - 1]
+            if i >= 2: acc -= y[s + i - 2]
+            if i >= 3: acc += y[s + i - 3]
+            y[s + i] = (acc + 32768) % 65536 - 32768
+    y = y.astype(np.int16)
+    r = optimise(ctx, dev(ctx, y), N, L, taps=(1, -2, 1, -1), search=1)
+    assert r["taps"] == taps, r["taps"]
+    opts = (r["m"], L, 4) + tuple(t & 0xFFFFFFFF for t in taps)
+    assert r["words"] == O.encode_batch(y, N, opts)[0].size
+    delta_words = min(int(w) for w in O_sizes(O, y, N, L))
+    assert r["words"] < 0.8 * delta_words  # (the point of a filter: well below the best delta coding)
+
+
+def O_sizes(O, x, N, L):
+    return [O.encode_batch(x, N, (1 << k, L))[0].size for k in range(1, 12)]
+
+
 def test_short_waveform_chunks_walk_through_lds(ctx, O):
     # many short waveforms per chunk: the header chain is walked inside an LDS block (k_walk_block)
     rng = np.random.default_rng(8)

@@ -393,7 +393,7 @@ def main():
                                    f"m={a.m}, {n_chunks} chunks of {W}x{L} per GPU, encode then decode, HBM resident",
                        "waveforms_per_gpu": n_waves, "wave_len": L, "rice_m": a.m, "chunks_per_gpu": n_chunks,
                        "decode_impl": a.decode_impl},
-            "compression_ratio": ratio,
+            "compression_ratio": ratio, "decode_path": plan.last_decode_path(), "encode_path": plan.last_encode_path(),
             "rank_devices": [r[1] for r in rank_info], "rank_encoded_bytes": [r[2] for r in rank_info],
             # per-GPU kernel times next to the wall time: what every rank measured with HIP events on its own stream
             "rank_kernel_ms": {"encode": [r[3] / 1e3 for r in rank_info], "decode": [r[4] / 1e3 for r in rank_info]},
@@ -401,7 +401,8 @@ def main():
             "encode_GBps": raw_bytes / (enc_ms[3] * 1e-3) / 1e9,
             "decode_GBps": raw_bytes / (dec_ms[3] * 1e-3) / 1e9,
             # HIP events on the codec's stream.  encode: [state memset | - | k_encode_stream];
-            # decode: [granule memset | k_decode_lanes (header-chain walk fused in)]
+            # decode: [the header-chain walk, k_walk_sparse: 64 chains per chunk | k_decode_lanes]  (decode_path says which
+            # decoders ran: DRX_PATH_LANES = behind a separate walk, DRX_PATH_LANES_FUSED = the walk inside the launch)
             "kernel_ms": {"encode_prepare": float(enc_ms[0] + enc_ms[1]), "encode_kernel": float(enc_ms[2]),
                           "decode_prepare": float(dec_ms[0]), "decode_kernel": float(dec_ms[1])},
             "roofline": {"bound": "hbm", "kernel": "k_decode_lanes", "achieved": achieved, "peak": HBM_PEAK_GBPS,
@@ -409,7 +410,10 @@ def main():
                          # true: the two rocprofv3 --pmc child passes ran in this session BEFORE the timed region (A/B scripts
                          # pass --no-collect; profiles/r04_notes.md has both forms measured on one box)
                          "traffic_collected_in_run": traffic_kernels is not None,
-                         "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": dec_kernel_ms},
+                         "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": dec_kernel_ms,
+                         # the same with the walk kernel in front of it counted in (it moves ~0.1 % of the bytes)
+                         "walk_ms": float(np.mean(np.array(coll["dec"])[:, 0])),
+                         "frac_with_walk": algo_bytes / ((dec_kernel_ms + float(np.mean(np.array(coll["dec"])[:, 0]))) * 1e-3) / 1e9 / HBM_PEAK_GBPS},
             "roofline_encode": {"bound": "hbm", "kernel": enc_kernel, "achieved": algo_bytes / (pack_ms * 1e-3) / 1e9,
                                 "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                 "frac": algo_bytes / (pack_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic_enc, "traffic_source": traffic_source,

@@ -1056,7 +1056,7 @@ uint64_t par_walk_scratch_bytes(const Geom &G) {
         const uint32_t nb = bw_walk_blocks_max(G);
         bw = nb != 0;
         bw_units = G.n_chunks * nb;
-        pw = !bw && G.n_chunks <= kPwMaxChunks && G.u_n_waves <= kPwMaxWaves && G.u_n_waves >= 64u && G.u_wave_len > kWalkShortLen;
+        pw = !bw && G.n_chunks <= kSwMaxChunks && G.u_n_waves <= kPwMaxWaves && G.u_n_waves >= 64u && G.u_wave_len > kWalkShortLen;
     } else {
         if (!G.rag_par) return 0;
         pw = G.n_long != 0;
@@ -1064,7 +1064,8 @@ uint64_t par_walk_scratch_bytes(const Geom &G) {
         bw_units = (uint64_t)G.n_short * G.rag_bw_blocks_max;
     }
     if (!pw && !bw) return 0;
-    return (pw ? G.n_chunks * kPwStride * sizeof(uint2) : 0) + (3u * G.n_chunks + 2u) * sizeof(uint32_t) +
+    // (the candidate lists of the scan form only where that form may run)
+    return (pw && G.n_chunks <= kPwMaxChunks ? G.n_chunks * kPwStride * sizeof(uint2) : 0) + (3u * G.n_chunks + 2u) * sizeof(uint32_t) +
            bw_units * (kWalkBlockWords / 1024u) * sizeof(BwBlock) +  // (blocks of 1024 words at the smallest)
            bw_units * bw_hop_bytes_per_block4096(G);                 // header lists of the first block pass
 }
@@ -1094,12 +1095,14 @@ static unsigned dec_lds_pad() {
 //   SIMPLE        | decode_impl 0; a filter the fast kernels do not take (> 4 taps, taps[0] != +-1)   | parallel walks / serial
 //   BLOCKS (+IIR) | few long waveforms (blocks_batch(): geometry and cost), delta or a fast filter    | parallel walks / serial
 //   LONG          | uniform, delta, long_waveform_batch() and not BLOCKS; flag 512                    | parallel walks / serial
-//   LANES fused   | decode_impl 8 (5), not a batch the parallel walks take, grid not mostly idle      | inside the launch
+//   LANES fused   | decode_impl 8 (5), not a batch the parallel walks take (short waveforms in many    | inside the launch
+//                 | chunks, chunks of more than 3584 or fewer than 64 waveforms), grid not mostly idle |
 //   LANES         | everything else; ragged batches behind both parallel walks: two launches          | parallel walks / serial
 //
 //   walk          | when (never with tables_ready: the caller filled wave_off / wave_words)
 //   --------------+-----------------------------------------------------------------------------------
-//   chunk-wide    | <= 224 chunks of <= 3584 waveforms longer than 2048 samples (uniform), the long-waveform chunks of a small ragged batch
+//   chunk-wide    | chunks of 64 ... 3584 waveforms longer than 2048 samples (uniform, any number of chunks: k_walk_sparse chases 64 chains per
+//                 | chunk without reading it -- the headline batch too), the long-waveform chunks of a small ragged batch
 //   block-parallel| bw_walk_blocks_max(): few chunks of many short waveforms (uniform), the short-waveform chunks of a small ragged batch
 //   serial        | otherwise: LDS block walkers (WaveformLength <= 2048) / scalar chains, one launch in front of the decoder
 // Flags: 256 never BLOCKS / LONG, 512 LONG instead of BLOCKS, 2048 never the parallel walks, 131072 one lanes launch behind both walks.
@@ -1126,7 +1129,7 @@ static DecodeRoute route_decode(const Geom &G, int impl, bool tables_ready, bool
 #endif
     const bool want_fused = !tables_ready && (impl == 5 || impl == 8);
     const bool no_par = tables_ready || !have_pw || (G.dbg & 2048u);
-    const bool par_walk = !no_par && G.uniform && G.n_chunks <= kPwMaxChunks && G.u_n_waves <= kPwMaxWaves && G.u_n_waves >= 64u &&
+    const bool par_walk = !no_par && G.uniform && G.n_chunks <= kSwMaxChunks && G.u_n_waves <= kPwMaxWaves && G.u_n_waves >= 64u &&
                           G.u_wave_len > kWalkShortLen;
     R.bw_blocks_max = bw_walk_blocks_max(G);
     const bool bw_walk = !no_par && R.bw_blocks_max != 0;
@@ -1189,7 +1192,8 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
         const uint32_t n_pw = G.uniform ? (uint32_t)G.n_chunks : G.n_long, n_bw = G.uniform ? (uint32_t)G.n_chunks : G.n_short;
         const uint32_t bwb = G.uniform ? R.bw_blocks_max : G.rag_bw_blocks_max;
         uint2 *cand = reinterpret_cast<uint2 *>(d_pw);
-        uint32_t *cnt = reinterpret_cast<uint32_t *>(cand + (use_pw ? G.n_chunks * kPwStride : 0));
+        const bool have_cand = use_pw && G.n_chunks <= kPwMaxChunks;  // (par_walk_scratch_bytes())
+        uint32_t *cnt = reinterpret_cast<uint32_t *>(cand + (have_cand ? G.n_chunks * kPwStride : 0));
         uint32_t *pw_fail = cnt + G.n_chunks, *bw_fail = pw_fail + G.n_chunks;
         BwBlock *info = reinterpret_cast<BwBlock *>(bw_fail + G.n_chunks + (G.n_chunks & 1u));
         hipError_t e = hipMemsetAsync(cnt, 0, 3u * G.n_chunks * sizeof(uint32_t), s);
@@ -1203,9 +1207,15 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
             if ((e = hipStreamWaitEvent(side->s, side->fork, 0)) != hipSuccess) return e;
         }
         if (use_pw) {
-            k_pw_scan<<<(unsigned)(n_pw * pw_parts(n_pw)), 256, 0, spw>>>(G, d_in, in_words, d_chunk_word_off, pw_list, cand, cnt, pw_parts(n_pw));
-            k_walk_parallel<<<n_pw, kPwThreads, 0, spw>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words,
-                                                          pw_fail, pw_list, cand, cnt, pw_parts(n_pw));
+            if (!(G.dbg & 8388608u) || !have_cand) {
+                // 64 chains per chunk chased in parallel from starts found by looking forward from 64 cuts (drx_walk.h): the chunk is
+                // not read
+                k_walk_sparse<<<n_pw, kSwThreads, 0, spw>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words, pw_fail, pw_list);
+            } else {
+                k_pw_scan<<<(unsigned)(n_pw * pw_parts(n_pw)), 256, 0, spw>>>(G, d_in, in_words, d_chunk_word_off, pw_list, cand, cnt, pw_parts(n_pw));
+                k_walk_parallel<<<n_pw, kPwThreads, 0, spw>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off, d_wave_words,
+                                                              pw_fail, pw_list, cand, cnt, pw_parts(n_pw));
+            }
             k_walk_scalar_only<<<blocks_for(G.n_chunks, kWalkChains), 64, 0, spw>>>(G, d_in, in_words, d_chunk_word_off, d_wave_off,
                                                                                     d_wave_words, d_status, pw_fail);
         }

@@ -51,6 +51,7 @@ struct Geom {
                    //  524288 k_encode_stream (encode_impl 2) whatever the batch (else: where stream_encoder_suits())
                    //  2097152 general filters behind the block decoder: always the separate k_iir_tiles pass
                    //  4194304 k_encode_stream_segs wherever the batch is uniform, segments of kEsSegMinLen samples
+                   //  8388608 the chunk-wide walk by reading the chunk (k_pw_scan + k_walk_parallel) instead of k_walk_sparse
                    // Ablation switches INSIDE the kernels, compiled only with -DDRX_ABLATION (results invalid):
                    //   decode:   1 skip the output stores   2 skip the stream loads
                    //             4 request pieces without counting on the round's minimum consumption   16384 long: no stores
@@ -320,8 +321,14 @@ constexpr uint32_t kWalkShortLenHost = 2048;  // keep equal to kWalkShortLen in 
 constexpr uint32_t kSegShortLenHost = 3072, kSegLongLenHost = 10240;
 // limits of the parallel header walks (see k_walk_parallel / k_bw_blocks)
 constexpr uint32_t kPwMaxWaves = 3584;   // waveforms per chunk the chunk-wide walk takes (leaves room for impostors)
-constexpr uint64_t kPwMaxChunks = 224;   // more chunks hide the serial walk behind the decoding, and reading the stream
-                                        // a second time costs more than it saves (measured crossover: ~260 chunks of 2000 x 7000)
+#ifndef DRX_PW_MAX_CHUNKS
+#define DRX_PW_MAX_CHUNKS 224
+#endif
+constexpr uint64_t kPwMaxChunks = DRX_PW_MAX_CHUNKS;  // the walks that READ the chunks (block-parallel; the chunk-wide walk's scan form,
+                                                      // debug flag 8388608): more chunks hide the serial walk behind the decoding
+// the chunk-wide walk by chains (k_walk_sparse) costs ~60 us per 512 chunks whatever their size: every uniform batch of
+// long waveforms takes it, the headline's 500 chunks included (4.74 + 0.08 ms against 5.33 with the walk inside the launch)
+constexpr uint64_t kSwMaxChunks = 1u << 20;
 
 }  // namespace drx
 #endif

@@ -389,6 +389,130 @@ __global__ __launch_bounds__(kPwThreads) void k_walk_parallel(Geom G, const uint
     if (tid == 0 && s_bad) fail[c] = 1u;
 }
 
+// ---------------------------------------------------------------------------
+// The chunk-wide walk WITHOUT reading the chunk (round 4): 64 chains per chunk, chased in parallel
+// ---------------------------------------------------------------------------
+// k_pw_scan reads every word of a chunk to find the ~2000 that are headers -- a second pass over the whole stream, 0.26 ms in
+// front of a 1.2 ms decode at 100 chunks, 0.48 at 224.  A chain needs none of that: a header says where the next one is.  What
+// a chain needs is a true header to START from, and those are easy to come by: a payload word practically never looks like
+// a length header (n_i lies in a range of a few thousand out of 2^32), so the first plausible word at or behind ANY position
+// is the next header.  The chunk is cut at 64 word positions; from each, one wavefront looks forward for the first plausible
+// word (on average half a waveform's code away); then 64 lanes chase their chains at once, each until it arrives at the next
+// lane's start -- which it must hit exactly: with lane 0 starting at the chunk's first header and the last chain ending at
+// the chunk's end, the chain of equalities proves every start a true header, as in the block-parallel walk.  W / 64 dependent
+// loads per lane instead of W, a few hundred KB read instead of the chunk.  Anything else (an impostor picked as a start, a
+// broken chain, a count that is not W) flags the chunk for the scalar walker, which also judges it.
+constexpr int kSwThreads = 1024;
+constexpr uint32_t kSwSegs = 64;    // chains per chunk
+constexpr uint32_t kSwCap = 96;     // headers a chain may collect (the average is W / 64 <= 56); 48 KB of LDS
+
+__global__ __launch_bounds__(kSwThreads) void k_walk_sparse(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
+                                                            const uint64_t *__restrict__ chunk_word_off,
+                                                            uint64_t *__restrict__ wave_off, uint32_t *__restrict__ wave_words,
+                                                            uint32_t *__restrict__ fail, const uint32_t *__restrict__ list) {
+    __shared__ uint32_t s_a[kSwSegs + 1];          // where chain s starts (word of the chunk); s_a[S] = the chunk's length
+    __shared__ uint32_t s_cnt[kSwSegs], s_base[kSwSegs + 1];
+    __shared__ uint2 s_list[kSwSegs][kSwCap];      // {position, n_i} of every header a chain found
+    __shared__ uint32_t s_bad;
+    const uint32_t tid = threadIdx.x;
+    const int lane = lane_id();
+    const uint32_t wv = tid >> 6;
+    const uint64_t c = list ? (uint64_t)list[blockIdx.x] : blockIdx.x;
+    uint32_t W, L, N;
+    uint64_t base;
+    if (G.uniform) { W = G.u_n_waves; L = G.u_wave_len; N = G.u_n_samples; base = c * W; }
+    else { const ChunkDesc d = G.chunks[c]; W = d.n_waves; L = d.wave_len; N = d.n_samples; base = d.wave_base; }
+    const uint64_t begin = chunk_word_off[c];
+    const uint64_t end = chunk_word_off[c + 1];
+    if (tid == 0) s_bad = 0;
+    bool ok = !(end > in_words || begin + 2 > end || end - begin > 0x7fffffffull);
+    if (ok && in[begin] != N) ok = false;
+    if (!ok) { if (tid == 0) fail[c] = 1u; return; }  // (uniform across the workgroup)
+    const uint32_t len_w = (uint32_t)(end - begin);
+    const uint32_t last_len = N - (W - 1u) * L;
+    const uint32_t max_full = max_payload_words(L), min_full = min_payload_words(L, G.k);
+    const uint32_t max_last = max_payload_words(last_len), min_last = min_payload_words(last_len, G.k);
+    const uint32_t lo_any = min_full < min_last ? min_full : min_last, hi_any = max_full > max_last ? max_full : max_last;
+    // chains: as many as give each a few waveforms
+    uint32_t S = W / 8u;
+    S = S > kSwSegs ? kSwSegs : (S < 1u ? 1u : S);
+    const uint32_t *cw = in + begin;  // the chunk's words
+    // ---- 1. a start for every chain: the first plausible header at or behind its cut ----
+    if (tid == 0) { s_a[0] = 1u; s_a[S] = len_w; }
+    auto plausible = [&](uint32_t v, uint32_t i) { return v >= lo_any && v <= hi_any && (uint64_t)i + 1u + v <= len_w; };
+    for (uint32_t sg = 1u + wv; sg < S; sg += kSwThreads / 64u) {
+        uint32_t from = 1u + (uint32_t)(((uint64_t)(len_w - 1u) * sg) / S);
+        uint32_t found = len_w;  // (none: the chains in front run to the chunk's end)
+        for (uint32_t tries = 0; tries < 64u; ++tries) {
+            constexpr uint32_t U = 8;
+            found = len_w;
+            for (uint32_t j0 = from; j0 < len_w && found == len_w; j0 += 64u * U) {
+                uint32_t v[U];
+#pragma unroll
+                for (uint32_t u = 0; u < U; ++u) {
+                    const uint32_t i = j0 + 64u * u + (uint32_t)lane;
+                    v[u] = i < len_w ? cw[i] : 0xffffffffu;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < U; ++u) {
+                    const uint64_t m = __ballot(plausible(v[u], j0 + 64u * u + (uint32_t)lane));
+                    if (m && found == len_w) found = j0 + 64u * u + (uint32_t)__builtin_ctzll(m);
+                }
+            }
+            if (found == len_w) break;
+            // a payload word is plausible once in a million, and this kernel looks at millions: a start counts only if the
+            // word it points to is plausible too (or the chunk's end): one dependent load per cut
+            const uint32_t nxt = found + 1u + cw[found];  // (<= len_w: plausible())
+            if (nxt == len_w || plausible(cw[nxt], nxt)) break;
+            from = found + 1u;
+            found = len_w;
+        }
+        if (lane == 0) s_a[sg] = found;
+    }
+    __syncthreads();
+    // ---- 2. the chases ----
+    if (tid < S) {
+        uint32_t pos = s_a[tid];
+        const uint32_t target = s_a[tid + 1u];
+        uint32_t cnt = 0;
+        bool bad = false;
+        while (pos < target) {
+            const uint32_t n = cw[pos];  // (pos < len_w: inside the chunk, and the chunk inside the stream)
+            if (n < lo_any || n > hi_any || cnt >= kSwCap) { bad = true; break; }
+            s_list[tid][cnt] = make_uint2(pos, n);
+            ++cnt;
+            pos += n + 1u;  // (<= len_w + hi_any: no overflow, chunks have fewer than 2^31 words)
+        }
+        if (pos != target) bad = true;  // (a chain must arrive exactly where the next one started)
+        s_cnt[tid] = cnt;
+        if (bad) atomicOr(&s_bad, 1u);
+    }
+    __syncthreads();
+    // ---- 3. waveform numbers, the tables ----
+    if (tid < 64u) {
+        const uint32_t cnt = tid < S ? s_cnt[tid] : 0u;
+        const uint32_t incl = wave_incl_scan_dpp(cnt);
+        s_base[tid] = incl - cnt;
+        if (tid == 63u) s_base[64] = incl;
+    }
+    __syncthreads();
+    if (s_bad || s_base[64] != W) { if (tid == 0) fail[c] = 1u; return; }
+    bool bad = false;
+    for (uint32_t sg = wv; sg < S; sg += kSwThreads / 64u) {
+        const uint32_t cnt = s_cnt[sg], b0 = s_base[sg];
+        for (uint32_t i = (uint32_t)lane; i < cnt; i += 64u) {
+            const uint2 e = s_list[sg][i];
+            const uint32_t w = b0 + i;
+            if (e.y > ((w + 1u == W) ? max_last : max_full) || e.y < ((w + 1u == W) ? min_last : min_full)) bad = true;
+            wave_off[base + w] = begin + e.x;
+            wave_words[base + w] = e.y;
+        }
+    }
+    if (bad) atomicOr(&s_bad, 1u);
+    __syncthreads();
+    if (tid == 0 && s_bad) fail[c] = 1u;
+}
+
 __global__ __launch_bounds__(64) void k_walk_list(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
                                                   const uint64_t *__restrict__ chunk_word_off,
                                                   const uint32_t *__restrict__ chunk_list, uint32_t n_list,

@@ -968,7 +968,7 @@ def test_corrupt_headers_through_the_parallel_walks(ctx, O):
         ref_w, ref_off = O.encode_batch(x, W * L, opts)
         plan = ctx.plan_uniform(n_chunks, W * L, opts)
         good = dr.EncodedBatch(dev(ctx, ref_w.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), ref_w.size)
-        for flags in (0, 2048):  # parallel walk / the serial walkers
+        for flags in (0, 8388608, 2048):  # parallel walks (chunk-wide: 64 chains chased / the chunk read) / the serial walkers
             ctx.set_option("debug_flags", flags)
             assert np.array_equal(plan.decode(good).cpu().numpy(), x)
         ctx.set_option("debug_flags", 0)
@@ -980,7 +980,7 @@ def test_corrupt_headers_through_the_parallel_walks(ctx, O):
             bad = ref_w.copy()
             bad[pos[which]] = (int(bad[pos[which]]) + delta) & 0xFFFFFFFF
             enc = dr.EncodedBatch(dev(ctx, bad.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), bad.size)
-            for flags in (0, 2048):
+            for flags in (0, 8388608, 2048):
                 ctx.set_option("debug_flags", flags)
                 with pytest.raises(dr.DeltaRiceError) as e:
                     plan.decode(enc)
@@ -990,6 +990,46 @@ def test_corrupt_headers_through_the_parallel_walks(ctx, O):
         bad[int(ref_off[1])] += 1  # the chunk's sample count
         with pytest.raises(dr.DeltaRiceError):
             plan.decode(dr.EncodedBatch(dev(ctx, bad.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), bad.size))
+
+
+def test_chunk_wide_walk_by_chains(ctx, O):
+    """k_walk_sparse: the chunk-wide header walk without reading the chunk -- 64 chains per chunk chased in parallel from starts
+    found by looking forward from 64 cuts for a plausible header (validated by the word it points to).  Shapes from few to
+    3584 waveforms per chunk, a shorter last waveform, data full of payload words that LOOK like headers (uniform noise under a
+    small RiceParameter: escapes whose 16 payload bits end in zeros, followed by eight more), waveforms of very different
+    code lengths in one chunk (a chain then collects more headers than its share: the scalar walker takes over), against
+    the walk that reads the chunk (flag 8388608) and the serial one (2048)."""
+    rng = np.random.default_rng(29)
+    cases = []
+    for L, W, n_chunks, kind in ((7000, 2000, 3, "gauss"), (2049, 3584, 2, "gauss"), (30000, 64, 4, "gauss"), (7000, 70, 2, "gauss"),
+                                 (5000, 400, 2, "uniform"), (4096, 1000, 2, "uniform"), (7000, 512, 2, "mixed")):
+        N = W * L - (L // 3 if W > 100 else 0)  # a shorter last waveform
+        if kind == "gauss":
+            x = rng.normal(0, 10, n_chunks * N).astype(np.int16)
+        elif kind == "uniform":
+            x = rng.integers(-32768, 32768, n_chunks * N).astype(np.int16)
+        else:  # the first three quarters of every chunk silent (one bit per sample at k = 0), the rest loud
+            x = rng.normal(0, 2000, n_chunks * N).astype(np.int16)
+            for c in range(n_chunks):
+                x[c * N:c * N + (3 * N) // 4] = 0
+        cases.append((L, W, n_chunks, N, kind, x))
+    for L, W, n_chunks, N, kind, x in cases:
+        k = 0 if kind == "mixed" else 3
+        opts = (1 << k, L)
+        ref_w, ref_off = O.encode_batch(x, N, opts)
+        plan = ctx.plan_uniform(n_chunks, N, opts)
+        enc = dr_batch(ctx, ref_w, ref_off)
+        for flags in (256, 256 | 8388608, 256 | 2048):  # (256: the lane-per-waveform decoder behind the walk, whatever the shape)
+            ctx.set_option("debug_flags", flags)
+            assert np.array_equal(plan.decode(enc).cpu().numpy(), x), (L, W, kind, flags)
+            nw = plan.wave_words()
+            assert int(nw.sum(dtype=np.uint64)) + nw.size + n_chunks == ref_w.size, (L, W, kind, flags)
+        ctx.set_option("debug_flags", 0)
+
+
+def dr_batch(ctx, ref_w, ref_off):
+    import deltarice_amd as dr
+    return dr.EncodedBatch(dev(ctx, ref_w.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), ref_w.size)
 
 
 def test_decode_with_the_encoders_table_as_a_side_band(ctx, O):

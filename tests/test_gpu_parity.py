@@ -1001,13 +1001,18 @@ def test_chunk_wide_walk_by_chains(ctx, O):
     the walk that reads the chunk (flag 8388608) and the serial one (2048)."""
     rng = np.random.default_rng(29)
     cases = []
-    for L, W, n_chunks, kind in ((7000, 2000, 3, "gauss"), (2049, 3584, 2, "gauss"), (30000, 64, 4, "gauss"), (7000, 70, 2, "gauss"),
-                                 (5000, 400, 2, "uniform"), (4096, 1000, 2, "uniform"), (7000, 512, 2, "mixed")):
+    for L, W, n_chunks, kind in ((7000, 2000, 6, "gauss"), (2049, 3584, 5, "gauss"), (30000, 64, 6, "gauss"), (7000, 70, 5, "gauss"),
+                                 (5000, 400, 5, "uniform"), (4096, 1000, 5, "uniform"), (7000, 512, 5, "mixed"),
+                                 # short waveforms (the block-parallel walk's: the same checks cost nothing here)
+                                 (512, 27343, 2, "gauss"), (2048, 6835, 2, "gauss"), (100, 60000, 1, "gauss"), (16, 65536, 1, "gauss"),
+                                 (300, 9000, 2, "uniform"), (1000, 1500, 2, "mixed"), (2048, 40, 1, "gauss"), (64, 3000, 1, "zeros")):
         N = W * L - (L // 3 if W > 100 else 0)  # a shorter last waveform
         if kind == "gauss":
             x = rng.normal(0, 10, n_chunks * N).astype(np.int16)
         elif kind == "uniform":
             x = rng.integers(-32768, 32768, n_chunks * N).astype(np.int16)
+        elif kind == "zeros":
+            x = np.zeros(n_chunks * N, np.int16)
         else:  # the first three quarters of every chunk silent (one bit per sample at k = 0), the rest loud
             x = rng.normal(0, 2000, n_chunks * N).astype(np.int16)
             for c in range(n_chunks):
@@ -1019,7 +1024,9 @@ def test_chunk_wide_walk_by_chains(ctx, O):
         ref_w, ref_off = O.encode_batch(x, N, opts)
         plan = ctx.plan_uniform(n_chunks, N, opts)
         enc = dr_batch(ctx, ref_w, ref_off)
-        for flags in (256, 256 | 8388608, 256 | 2048):  # (256: the lane-per-waveform decoder behind the walk, whatever the shape)
+        # (256: the lane-per-waveform decoder behind the walk, whatever the shape; the other flags: the walks that read the chunks,
+        # the serial walkers)
+        for flags in (256, 256 | 8388608, 256 | 2048):
             ctx.set_option("debug_flags", flags)
             assert np.array_equal(plan.decode(enc).cpu().numpy(), x), (L, W, kind, flags)
             nw = plan.wave_words()

@@ -447,11 +447,12 @@ drx_status drx_plan_create(drx_ctx *ctx, uint64_t n_chunks, const uint32_t *chun
         {
             bool ok = p->n_long <= kPwMaxChunks && p->n_short <= kPwMaxChunks;
             uint64_t bmax = 0;
-            uint32_t min_len = 0xffffffffu;
+            uint32_t min_len = 0xffffffffu, min_long_waves = 0xffffffffu;
             for (uint64_t c = 0; c < n_chunks && ok; ++c) {
                 const ChunkDesc &d = desc[c];
                 if (d.wave_len > kWalkShortLenHost) {
                     ok = d.n_waves <= kPwMaxWaves;
+                    min_long_waves = std::min(min_long_waves, d.n_waves);
                 } else {
                     ok = d.wave_len >= 16u && p->n_short <= d.n_waves / 35u;
                     const uint64_t mw = 1u + 2ull * d.n_waves + (((uint64_t)d.n_samples * 25u + 31u) >> 5);
@@ -462,6 +463,7 @@ drx_status drx_plan_create(drx_ctx *ctx, uint64_t n_chunks, const uint32_t *chun
             p->G.rag_par = ok && bmax <= 0xfffffu;
             p->G.rag_bw_blocks_max = (uint32_t)bmax;
             p->G.rag_bw_min_len = min_len;
+            p->G.rag_pw_min_waves = min_long_waves;
         }
         // the segment encoder for ragged batches with short (<= 2048) or long (>= 16384) waveforms somewhere: unit
         // (waveform x 8192-sample segment slot) numbering per chunk

@@ -85,6 +85,7 @@ struct Geom {
     // rag_bw_blocks_max = 4096-word blocks of the largest short-waveform chunk at 25 bits per sample
     uint32_t rag_par, rag_bw_blocks_max;
     uint32_t rag_bw_min_len;  // ... and the smallest WaveformLength among those chunks (bounds the headers of a block)
+    uint32_t rag_pw_min_waves;  // ... and the fewest waveforms any LONG-waveform chunk has (k_walk_sparse: from 64 on)
     // ragged batches, lane-per-waveform decode outside the fused launch: {chunk, group of 64 waveforms} of every
     // wavefront, longest WaveformLength first; rag_groups entries
     const uint2 *rag_order;

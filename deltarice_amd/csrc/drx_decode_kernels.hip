@@ -1209,7 +1209,8 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
         if (use_pw) {
             // (up to four chunks the scan form is quicker: 128 workgroups read one chunk in 11 us, where a chain is 31 dependent loads)
             // ... and chunks of a few very long waveforms (ragged batches): a start costs half a waveform's code in reads
-            const bool chains_suit = n_pw > 4u && (G.uniform || G.rag_pw_min_waves >= 64u);
+            // (debug flag 16777216: chains whatever the batch -- the tests' small batches)
+            const bool chains_suit = (G.dbg & 16777216u) || (n_pw > 4u && (G.uniform || G.rag_pw_min_waves >= 64u));
             if ((!(G.dbg & 8388608u) && chains_suit) || !have_cand) {
                 // 64 chains per chunk chased in parallel from starts found by looking forward from 64 cuts (drx_walk.h): the chunk is
                 // not read

@@ -52,6 +52,7 @@ struct Geom {
                    //  2097152 general filters behind the block decoder: always the separate k_iir_tiles pass
                    //  4194304 k_encode_stream_segs wherever the batch is uniform, segments of kEsSegMinLen samples
                    //  8388608 the chunk-wide walk by reading the chunk (k_pw_scan + k_walk_parallel) instead of k_walk_sparse
+                   // 16777216 k_walk_sparse also for one to four chunks and for ragged chunks of few long waveforms
                    // Ablation switches INSIDE the kernels, compiled only with -DDRX_ABLATION (results invalid):
                    //   decode:   1 skip the output stores   2 skip the stream loads
                    //             4 request pieces without counting on the round's minimum consumption   16384 long: no stores

@@ -201,7 +201,8 @@ drx_status drx_plan_last_timings(drx_plan *plan, float ms[4]);
  *        524288 the persistent encoder (encode_impl 2) whatever the batch's size and expected code length,
  *        2097152 general filters behind the block decoder: always the separate inverse-filter pass,
  *        4194304 the persistent encoder's segment form (long waveforms) wherever the batch is uniform, in segments of ~1024
- *        samples, 8388608 the chunk-wide header walk by reading the whole chunk instead of chasing 64 chains.  (Ablation switches inside the kernels exist only in -DDRX_ABLATION builds.) */
+ *        samples, 8388608 the chunk-wide header walk by reading the whole chunk instead of chasing 64 chains, 16777216 by
+ *        chains also where the scan form is the default (one to four chunks).  (Ablation switches inside the kernels exist only in -DDRX_ABLATION builds.) */
 drx_status drx_ctx_set_option(drx_ctx *ctx, const char *key, int64_t value);
 
 #ifdef __cplusplus

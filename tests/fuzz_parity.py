@@ -118,7 +118,8 @@ def main():
             expect = x
             if not lossless:
                 expect = np.concatenate([O.decode_chunk(ww, oo) for ww, oo in zip(words, copts)])
-            for flags, impl in ((0, 8), (256, 8), (512, 8), (0, 7), (256, 7), (0, 0), (131072, 8)):
+            # (16777216: the chunk-wide walk by chains also for these few chunks; 8388608: by reading the chunks)
+            for flags, impl in ((0, 8), (256, 8), (512, 8), (0, 7), (256, 7), (0, 0), (131072, 8), (256 | 16777216, 8), (256 | 8388608, 8)):
                 ctx.set_option("debug_flags", flags)
                 ctx.set_option("decode_impl", impl)
                 log(f"  decode flags {flags} impl {impl}")
@@ -149,7 +150,7 @@ def main():
                     if j not in hdr:
                         bad[j] ^= np.uint32(1 << int(rng.integers(0, 32)))
                 encb = dr.EncodedBatch(dev(ctx, bad.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), bad.size)
-                for flags, impl in ((0, 8), (256, 8), (512, 8), (0, 7), (0, 0)):
+                for flags, impl in ((0, 8), (256, 8), (512, 8), (0, 7), (0, 0), (256 | 16777216, 8)):
                     ctx.set_option("debug_flags", flags)
                     ctx.set_option("decode_impl", impl)
                     log(f"  corrupt decode flags {flags} impl {impl}")

@@ -968,7 +968,7 @@ def test_corrupt_headers_through_the_parallel_walks(ctx, O):
         ref_w, ref_off = O.encode_batch(x, W * L, opts)
         plan = ctx.plan_uniform(n_chunks, W * L, opts)
         good = dr.EncodedBatch(dev(ctx, ref_w.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), ref_w.size)
-        for flags in (0, 8388608, 2048):  # parallel walks (chunk-wide: 64 chains chased / the chunk read) / the serial walkers
+        for flags in (0, 16777216, 8388608, 2048):  # parallel walks (chunk-wide: 64 chains chased / the chunk read) / the serial walkers
             ctx.set_option("debug_flags", flags)
             assert np.array_equal(plan.decode(good).cpu().numpy(), x)
         ctx.set_option("debug_flags", 0)
@@ -980,7 +980,7 @@ def test_corrupt_headers_through_the_parallel_walks(ctx, O):
             bad = ref_w.copy()
             bad[pos[which]] = (int(bad[pos[which]]) + delta) & 0xFFFFFFFF
             enc = dr.EncodedBatch(dev(ctx, bad.view(np.int32)), dev(ctx, ref_off.astype(np.int64)), bad.size)
-            for flags in (0, 8388608, 2048):
+            for flags in (0, 16777216, 8388608, 2048):
                 ctx.set_option("debug_flags", flags)
                 with pytest.raises(dr.DeltaRiceError) as e:
                     plan.decode(enc)
@@ -1026,7 +1026,7 @@ def test_chunk_wide_walk_by_chains(ctx, O):
         enc = dr_batch(ctx, ref_w, ref_off)
         # (256: the lane-per-waveform decoder behind the walk, whatever the shape; the other flags: the walks that read the chunks,
         # the serial walkers)
-        for flags in (256, 256 | 8388608, 256 | 2048):
+        for flags in (256, 256 | 16777216, 256 | 8388608, 256 | 2048):
             ctx.set_option("debug_flags", flags)
             assert np.array_equal(plan.decode(enc).cpu().numpy(), x), (L, W, kind, flags)
             nw = plan.wave_words()

@@ -47,8 +47,10 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level par
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    # (the driver's round-end command is --steps 20 --warmup 5; the kernels of the first three or four steps of a process run
+    # 5-15 % slower than the rest -- profiles/r04_notes.md section 15 -- so the defaults are the same)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--waves", type=int, default=1_000_000, help="waveforms per GPU")
     ap.add_argument("--wave-len", type=int, default=7000)
     ap.add_argument("--chunk-waves", type=int, default=2000, help="waveforms per HDF5 chunk")

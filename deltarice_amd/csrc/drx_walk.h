@@ -439,14 +439,18 @@ __global__ __launch_bounds__(kSwThreads) void k_walk_sparse(Geom G, const uint32
     const uint32_t *cw = in + begin;  // the chunk's words
     // ---- 1. a start for every chain: the first plausible header at or behind its cut ----
     if (tid == 0) { s_a[0] = 1u; s_a[S] = len_w; }
+    __syncthreads();  // (s_bad is cleared before any wavefront may raise it)
     auto plausible = [&](uint32_t v, uint32_t i) { return v >= lo_any && v <= hi_any && (uint64_t)i + 1u + v <= len_w; };
     for (uint32_t sg = 1u + wv; sg < S; sg += kSwThreads / 64u) {
         uint32_t from = 1u + (uint32_t)(((uint64_t)(len_w - 1u) * sg) / S);
+        // (a waveform's code is at most hi_any words: a stream without a header in twice that is corrupt, and is not read to its end
+        // by every cut)
+        const uint32_t stop = (uint64_t)from + 2u * (hi_any + 2u) < len_w ? from + 2u * (hi_any + 2u) : len_w;
         uint32_t found = len_w;  // (none: the chains in front run to the chunk's end)
         for (uint32_t tries = 0; tries < 64u; ++tries) {
             constexpr uint32_t U = 8;
             found = len_w;
-            for (uint32_t j0 = from; j0 < len_w && found == len_w; j0 += 64u * U) {
+            for (uint32_t j0 = from; j0 < stop && found == len_w; j0 += 64u * U) {
                 uint32_t v[U];
 #pragma unroll
                 for (uint32_t u = 0; u < U; ++u) {
@@ -459,7 +463,11 @@ __global__ __launch_bounds__(kSwThreads) void k_walk_sparse(Geom G, const uint32
                     if (m && found == len_w) found = j0 + 64u * u + (uint32_t)__builtin_ctzll(m);
                 }
             }
-            if (found == len_w) break;
+            if (found >= stop) {  // (nothing in front of the stop)
+                if (stop < len_w && lane == 0) atomicOr(&s_bad, 1u);
+                found = len_w;
+                break;
+            }
             // a payload word is plausible once in a million, and this kernel looks at millions: a start counts only if the
             // word it points to is plausible too (or the chunk's end): one dependent load per cut
             const uint32_t nxt = found + 1u + cw[found];  // (<= len_w: plausible())

@@ -189,8 +189,10 @@ drx_status drx_plan_last_timings(drx_plan *plan, float ms[4]);
  *                  a scanner workgroup for the prefix sum) wherever the standard geometry applies;
  *                  1: single pass with a look-back per workgroup everywhere (round 3's form);  0: size pass + scan + pack pass
  *   "decode_impl"  variant of the lane-per-waveform decode; each is bit-exact and covered by the parity tests:
- *        8 (default)  header walk inside the launch where the batch is large enough to hide it
- *        7            the same kernel behind a separate walk kernel
+ *        8 (default)  behind the parallel header walks where a batch takes them (chunks of 64 ... 3584 waveforms longer than 2048
+ *                     samples, whatever their number: 64 chains per chunk are chased at once; few chunks of short waveforms);
+ *                     otherwise the header walk inside the launch where the batch is large enough to hide it
+ *        7            always behind a separate walk kernel
  *        0            simple kernel (also: general filters the staged kernel does not take)
  *        (5 / 1: one sample per ring access, the form 8 / 7 superseded in round 1 -- only in builds made with -DDRX_LEGACY)
  *   "debug_flags"  dispatch overrides that force an alternative (still bit-exact) path, for tests and A/B timing:

@@ -404,7 +404,8 @@ __global__ __launch_bounds__(kPwThreads) void k_walk_parallel(Geom G, const uint
 // broken chain, a count that is not W) flags the chunk for the scalar walker, which also judges it.
 constexpr int kSwThreads = 1024;
 constexpr uint32_t kSwSegs = 64;    // chains per chunk
-constexpr uint32_t kSwCap = 96;     // headers a chain may collect (the average is W / 64 <= 56); 48 KB of LDS
+constexpr uint32_t kSwCap = 192;    // headers a chain may collect: chains are equal in WORDS, so one through quiet waveforms holds more than
+                                    // the average W / 64 <= 56 -- up to 3.4 x (W = 2000: 6 x) before the scalar walker has to take the chunk; 48 KB of LDS
 
 __global__ __launch_bounds__(kSwThreads) void k_walk_sparse(Geom G, const uint32_t *__restrict__ in, uint64_t in_words,
                                                             const uint64_t *__restrict__ chunk_word_off,
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(kSwThreads) void k_walk_sparse(Geom G, const uint32
                                                             uint32_t *__restrict__ fail, const uint32_t *__restrict__ list) {
     __shared__ uint32_t s_a[kSwSegs + 1];          // where chain s starts (word of the chunk); s_a[S] = the chunk's length
     __shared__ uint32_t s_cnt[kSwSegs], s_base[kSwSegs + 1];
-    __shared__ uint2 s_list[kSwSegs][kSwCap];      // {position, n_i} of every header a chain found
+    __shared__ uint32_t s_list[kSwSegs][kSwCap];   // position of every header a chain found (n_i = the distance to the next one - 1)
     __shared__ uint32_t s_bad;
     const uint32_t tid = threadIdx.x;
     const int lane = lane_id();
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(kSwThreads) void k_walk_sparse(Geom G, const uint32
         while (pos < target) {
             const uint32_t n = cw[pos];  // (pos < len_w: inside the chunk, and the chunk inside the stream)
             if (n < lo_any || n > hi_any || cnt >= kSwCap) { bad = true; break; }
-            s_list[tid][cnt] = make_uint2(pos, n);
+            s_list[tid][cnt] = pos;
             ++cnt;
             pos += n + 1u;  // (<= len_w + hi_any: no overflow, chunks have fewer than 2^31 words)
         }
@@ -509,11 +510,12 @@ __global__ __launch_bounds__(kSwThreads) void k_walk_sparse(Geom G, const uint32
     for (uint32_t sg = wv; sg < S; sg += kSwThreads / 64u) {
         const uint32_t cnt = s_cnt[sg], b0 = s_base[sg];
         for (uint32_t i = (uint32_t)lane; i < cnt; i += 64u) {
-            const uint2 e = s_list[sg][i];
+            const uint32_t at = s_list[sg][i];
+            const uint32_t n = (i + 1u < cnt ? s_list[sg][i + 1u] : s_a[sg + 1u]) - at - 1u;  // (the chain arrived at the next one's start)
             const uint32_t w = b0 + i;
-            if (e.y > ((w + 1u == W) ? max_last : max_full) || e.y < ((w + 1u == W) ? min_last : min_full)) bad = true;
-            wave_off[base + w] = begin + e.x;
-            wave_words[base + w] = e.y;
+            if (n > ((w + 1u == W) ? max_last : max_full) || n < ((w + 1u == W) ? min_last : min_full)) bad = true;
+            wave_off[base + w] = begin + at;
+            wave_words[base + w] = n;
         }
     }
     if (bad) atomicOr(&s_bad, 1u);

@@ -402,7 +402,7 @@ __global__ __launch_bounds__(kPwThreads) void k_walk_parallel(Geom G, const uint
 // the chunk's end, the chain of equalities proves every start a true header, as in the block-parallel walk.  W / 64 dependent
 // loads per lane instead of W, a few hundred KB read instead of the chunk.  Anything else (an impostor picked as a start, a
 // broken chain, a count that is not W) flags the chunk for the scalar walker, which also judges it.
-constexpr int kSwThreads = 1024;
+constexpr int kSwThreads = 1024;     // (at most: chunks of few waveforms get 256, the kernel strides by blockDim)
 constexpr uint32_t kSwSegs = 64;    // chains per chunk
 constexpr uint32_t kSwCap = 192;    // headers a chain may collect: chains are equal in WORDS, so one through quiet waveforms holds more than
                                     // the average W / 64 <= 56 -- up to 3.4 x (W = 2000: 6 x) before the scalar walker has to take the chunk; 48 KB of LDS
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(kSwThreads) void k_walk_sparse(Geom G, const uint32
     if (tid == 0) { s_a[0] = 1u; s_a[S] = len_w; }
     __syncthreads();  // (s_bad is cleared before any wavefront may raise it)
     auto plausible = [&](uint32_t v, uint32_t i) { return v >= lo_any && v <= hi_any && (uint64_t)i + 1u + v <= len_w; };
-    for (uint32_t sg = 1u + wv; sg < S; sg += kSwThreads / 64u) {
+    for (uint32_t sg = 1u + wv; sg < S; sg += blockDim.x >> 6) {
         uint32_t from = 1u + (uint32_t)(((uint64_t)(len_w - 1u) * sg) / S);
         // (a waveform's code is at most hi_any words: a stream without a header in twice that is corrupt, and is not read to its end
         // by every cut)
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(kSwThreads) void k_walk_sparse(Geom G, const uint32
     __syncthreads();
     if (s_bad || s_base[64] != W) { if (tid == 0) fail[c] = 1u; return; }
     bool bad = false;
-    for (uint32_t sg = wv; sg < S; sg += kSwThreads / 64u) {
+    for (uint32_t sg = wv; sg < S; sg += blockDim.x >> 6) {
         const uint32_t cnt = s_cnt[sg], b0 = s_base[sg];
         for (uint32_t i = (uint32_t)lane; i < cnt; i += 64u) {
             const uint32_t at = s_list[sg][i];

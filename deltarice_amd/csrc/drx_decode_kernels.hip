@@ -1096,7 +1096,7 @@ static unsigned dec_lds_pad() {
 //   BLOCKS (+IIR) | few long waveforms (blocks_batch(): geometry and cost), delta or a fast filter    | parallel walks / serial
 //   LONG          | uniform, delta, long_waveform_batch() and not BLOCKS; flag 512                    | parallel walks / serial
 //   LANES fused   | decode_impl 8 (5), not a batch the parallel walks take (short waveforms in many    | inside the launch
-//                 | chunks, chunks of more than 3584 or fewer than 64 waveforms), grid not mostly idle |
+//                 | chunks, chunks of more than 3584 or fewer than 8 waveforms), grid not mostly idle |
 //   LANES         | everything else; ragged batches behind both parallel walks: two launches          | parallel walks / serial
 //
 //   walk          | when (never with tables_ready: the caller filled wave_off / wave_words)

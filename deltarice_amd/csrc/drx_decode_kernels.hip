@@ -1033,7 +1033,7 @@ uint32_t bw_walk_blocks_max(const Geom &G) {
     const uint64_t limit = G.u_n_waves / per < cap ? G.u_n_waves / per : cap;
     // every 4096-word block must hold a header: n_i <= 25 L / 32 < 4096, i.e. L <= 5000; chunks of longer
     // waveforms within the chunk-wide walk's capacity take that one
-    const bool chunk_wide = G.u_wave_len > kWalkShortLen && G.u_n_waves <= kPwMaxWaves && G.u_n_waves >= kSwMinWaves;
+    const bool chunk_wide = G.u_wave_len > kWalkShortLen && G.u_n_waves <= kSwMaxWaves && G.u_n_waves >= kSwMinWaves;
     if (!(G.uniform && G.n_chunks <= limit && G.u_wave_len <= 5000u && G.u_wave_len >= 16u && !chunk_wide)) return 0;
     const uint64_t max_words = 1u + G.u_n_waves + (((uint64_t)G.u_n_samples * 25u + 31u) >> 5) + G.u_n_waves;
     const uint64_t nb = (max_words + kWalkBlockWords - 1u) / kWalkBlockWords;
@@ -1056,7 +1056,7 @@ uint64_t par_walk_scratch_bytes(const Geom &G) {
         const uint32_t nb = bw_walk_blocks_max(G);
         bw = nb != 0;
         bw_units = G.n_chunks * nb;
-        pw = !bw && G.n_chunks <= kSwMaxChunks && G.u_n_waves <= kPwMaxWaves && G.u_n_waves >= kSwMinWaves && G.u_wave_len > kWalkShortLen;
+        pw = !bw && G.n_chunks <= kSwMaxChunks && G.u_n_waves <= kSwMaxWaves && G.u_n_waves >= kSwMinWaves && G.u_wave_len > kWalkShortLen;
     } else {
         if (!G.rag_par) return 0;
         pw = G.n_long != 0;
@@ -1096,12 +1096,12 @@ static unsigned dec_lds_pad() {
 //   BLOCKS (+IIR) | few long waveforms (blocks_batch(): geometry and cost), delta or a fast filter    | parallel walks / serial
 //   LONG          | uniform, delta, long_waveform_batch() and not BLOCKS; flag 512                    | parallel walks / serial
 //   LANES fused   | decode_impl 8 (5), not a batch the parallel walks take (short waveforms in many    | inside the launch
-//                 | chunks, chunks of more than 3584 or fewer than 8 waveforms), grid not mostly idle |
+//                 | chunks, chunks of more than 8192 or fewer than 8 waveforms), grid not mostly idle |
 //   LANES         | everything else; ragged batches behind both parallel walks: two launches          | parallel walks / serial
 //
 //   walk          | when (never with tables_ready: the caller filled wave_off / wave_words)
 //   --------------+-----------------------------------------------------------------------------------
-//   chunk-wide    | chunks of 8 ... 3584 waveforms longer than 2048 samples (uniform, any number of chunks: k_walk_sparse chases 64 chains per
+//   chunk-wide    | chunks of 8 ... 8192 waveforms longer than 2048 samples (uniform, any number of chunks: k_walk_sparse chases 64 chains per
 //                 | chunk without reading it -- the headline batch too), the long-waveform chunks of a small ragged batch
 //   block-parallel| bw_walk_blocks_max(): few chunks of many short waveforms (uniform), the short-waveform chunks of a small ragged batch
 //   serial        | otherwise: LDS block walkers (WaveformLength <= 2048) / scalar chains, one launch in front of the decoder
@@ -1129,7 +1129,7 @@ static DecodeRoute route_decode(const Geom &G, int impl, bool tables_ready, bool
 #endif
     const bool want_fused = !tables_ready && (impl == 5 || impl == 8);
     const bool no_par = tables_ready || !have_pw || (G.dbg & 2048u);
-    const bool par_walk = !no_par && G.uniform && G.n_chunks <= kSwMaxChunks && G.u_n_waves <= kPwMaxWaves && G.u_n_waves >= kSwMinWaves &&
+    const bool par_walk = !no_par && G.uniform && G.n_chunks <= kSwMaxChunks && G.u_n_waves <= kSwMaxWaves && G.u_n_waves >= kSwMinWaves &&
                           G.u_wave_len > kWalkShortLen;
     R.bw_blocks_max = bw_walk_blocks_max(G);
     const bool bw_walk = !no_par && R.bw_blocks_max != 0;
@@ -1210,7 +1210,7 @@ hipError_t launch_decode(const Geom &G, const uint32_t *d_in, uint64_t in_words,
             // (up to four chunks the scan form is quicker: 128 workgroups read one chunk in 11 us, where a chain is 31 dependent loads)
             // ... and chunks of a few very long waveforms (ragged batches): a start costs half a waveform's code in reads
             // (debug flag 16777216: chains whatever the batch -- the tests' small batches)
-            const bool few_waves = G.uniform && G.u_n_waves < 64u;  // (below the scan form's range)
+            const bool few_waves = G.uniform && (G.u_n_waves < 64u || G.u_n_waves > kPwMaxWaves);  // (outside the scan form's range)
             const bool chains_suit = (G.dbg & 16777216u) || few_waves || (n_pw > 4u && (G.uniform || G.rag_pw_min_waves >= 64u));
             if ((!(G.dbg & 8388608u) && chains_suit) || !have_cand || few_waves) {
                 // 64 chains per chunk chased in parallel from starts found by looking forward from 64 cuts (drx_walk.h): the chunk is

@@ -331,7 +331,7 @@ constexpr uint64_t kPwMaxChunks = DRX_PW_MAX_CHUNKS;  // the walks that READ the
 // the chunk-wide walk by chains (k_walk_sparse) costs ~60 us per 512 chunks whatever their size: every uniform batch of
 // long waveforms takes it, the headline's 500 chunks included (4.74 + 0.08 ms against 5.33 with the walk inside the launch)
 constexpr uint64_t kSwMaxChunks = 1u << 20;
-constexpr uint32_t kSwMinWaves = 8;  // ... from eight waveforms per chunk on (its scan form: from 64)
+constexpr uint32_t kSwMinWaves = 8, kSwMaxWaves = 8192;  // ... chunks of 8 ... 8192 waveforms (its scan form: 64 ... kPwMaxWaves)
 
 }  // namespace drx
 #endif

@@ -189,7 +189,7 @@ drx_status drx_plan_last_timings(drx_plan *plan, float ms[4]);
  *                  a scanner workgroup for the prefix sum) wherever the standard geometry applies;
  *                  1: single pass with a look-back per workgroup everywhere (round 3's form);  0: size pass + scan + pack pass
  *   "decode_impl"  variant of the lane-per-waveform decode; each is bit-exact and covered by the parity tests:
- *        8 (default)  behind the parallel header walks where a batch takes them (chunks of 8 ... 3584 waveforms longer than 2048
+ *        8 (default)  behind the parallel header walks where a batch takes them (chunks of 8 ... 8192 waveforms longer than 2048
  *                     samples, whatever their number: 64 chains per chunk are chased at once; few chunks of short waveforms);
  *                     otherwise the header walk inside the launch where the batch is large enough to hide it
  *        7            always behind a separate walk kernel

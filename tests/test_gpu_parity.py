@@ -1002,6 +1002,7 @@ def test_chunk_wide_walk_by_chains(ctx, O):
     rng = np.random.default_rng(29)
     cases = []
     for L, W, n_chunks, kind in ((7000, 2000, 6, "gauss"), (2049, 3584, 5, "gauss"), (30000, 64, 6, "gauss"), (7000, 70, 5, "gauss"),
+                                 (2100, 5000, 2, "gauss"), (2049, 8192, 1, "gauss"), (7000, 20, 30, "gauss"), (9000, 8, 12, "uniform"),
                                  (5000, 400, 5, "uniform"), (4096, 1000, 5, "uniform"), (7000, 512, 5, "mixed"),
                                  # short waveforms (the block-parallel walk's: the same checks cost nothing here)
                                  (512, 27343, 2, "gauss"), (2048, 6835, 2, "gauss"), (100, 60000, 1, "gauss"), (16, 65536, 1, "gauss"),

@@ -2,7 +2,7 @@ import os, sys, numpy as np, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 import deltarice_amd as dr
 ctx = dr.Context(0); ctx.set_option("profile", 1)
-for W, n_chunks in ((100, 2000), (64, 3000), (20, 10000), (500, 400)):
+for W, n_chunks in ((100, 2000), (64, 3000), (20, 10000), (500, 400), (5000, 40), (8000, 25)):
     L = 7000; N = W * L
     x = (torch.randn(n_chunks * N, device=ctx.device) * 10).to(torch.int16)
     torch.cuda.synchronize()

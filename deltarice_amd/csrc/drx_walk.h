@@ -434,9 +434,11 @@ __global__ __launch_bounds__(kSwThreads) void k_walk_sparse(Geom G, const uint32
     const uint32_t max_full = max_payload_words(L), min_full = min_payload_words(L, G.k);
     const uint32_t max_last = max_payload_words(last_len), min_last = min_payload_words(last_len, G.k);
     const uint32_t lo_any = min_full < min_last ? min_full : min_last, hi_any = max_full > max_last ? max_full : max_last;
-    // chains: as many as give each a few waveforms
+    // chains: as many as give each a few waveforms -- and only where finding a start (half a waveform's code, read by one wavefront
+    // 512 words at a time) costs less than the hops it saves: chunks of 32 x 500 000 samples are one chain of 32 hops
     uint32_t S = W / 8u;
     S = S > kSwSegs ? kSwSegs : (S < 1u ? 1u : S);
+    if (len_w / W > 8192u) S = 1u;
     const uint32_t *cw = in + begin;  // the chunk's words
     // ---- 1. a start for every chain: the first plausible header at or behind its cut ----
     if (tid == 0) { s_a[0] = 1u; s_a[S] = len_w; }

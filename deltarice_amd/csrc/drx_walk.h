@@ -965,30 +965,46 @@ __global__ __launch_bounds__(64) void k_bw_scan(Geom G, const uint32_t *__restri
     if (n_blocks > blocks_max) bad = true;
     BwBlock *my = info + pre[slot];
     uint32_t run = 0;
-    for (uint32_t b0 = 0; b0 < n_blocks && !bad; b0 += 64) {
-        const uint32_t b = b0 + (uint32_t)lane;
-        BwBlock o{0xffffffffu, 0, 0, 0};
-        if (b < n_blocks) o = my[b];
-        // every block must have been entered, start where its predecessor left, and the ends must be the chunk's
-        uint32_t prev_exit = (uint32_t)__shfl_up((int)o.exit, 1);
-        if (lane == 0) prev_exit = b0 ? my[b0 - 1u].exit : 1u;
-        bool lane_bad = false;
-        if (b < n_blocks) {
-            if (b + 1u == n_blocks && b > 0u && prev_exit == len_w) {
-                // the chain already ended inside the previous block: the last block is the tail of the last payload and
-                // has no header of its own (whatever small word it may hold is not one)
-                o.count = 0;
-                my[b].entry = 0xffffffffu;
-                my[b].count = 0;
-            } else {
-                lane_bad = o.entry == 0xffffffffu || o.entry != prev_exit;
-                if (b + 1u == n_blocks && o.exit != len_w) lane_bad = true;
-            }
+    uint32_t carry_exit = 1u;  // where the block in front of this group of 64 left (the first header follows the chunk's)
+    // (four groups' records in flight: one wavefront per chunk, 88 groups for config 5's chunks -- a dependent 16-byte load per
+    // group was the kernel's whole time, 0.065 ms)
+    constexpr uint32_t UG = 4;
+    for (uint32_t g0 = 0; g0 < n_blocks && !bad; g0 += 64u * UG) {
+        BwBlock og[UG];
+#pragma unroll
+        for (uint32_t u = 0; u < UG; ++u) {
+            const uint32_t b = g0 + 64u * u + (uint32_t)lane;
+            og[u] = BwBlock{0xffffffffu, 0, 0, 0};
+            if (b < n_blocks) og[u] = my[b];
         }
-        if (__any(lane_bad)) { bad = true; break; }
-        const uint32_t inc = wave_incl_scan_dpp(b < n_blocks ? o.count : 0u);
-        if (b < n_blocks) my[b].base = run + inc - o.count;
-        run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+#pragma unroll
+        for (uint32_t u = 0; u < UG; ++u) {
+            const uint32_t b0 = g0 + 64u * u;
+            if (b0 >= n_blocks || bad) break;  // (wave uniform)
+            const uint32_t b = b0 + (uint32_t)lane;
+            BwBlock o = og[u];
+            // every block must have been entered, start where its predecessor left, and the ends must be the chunk's
+            uint32_t prev_exit = (uint32_t)__shfl_up((int)o.exit, 1);
+            if (lane == 0) prev_exit = carry_exit;
+            carry_exit = (uint32_t)__builtin_amdgcn_readlane((int)o.exit, 63);
+            bool lane_bad = false;
+            if (b < n_blocks) {
+                if (b + 1u == n_blocks && b > 0u && prev_exit == len_w) {
+                    // the chain already ended inside the previous block: the last block is the tail of the last payload and
+                    // has no header of its own (whatever small word it may hold is not one)
+                    o.count = 0;
+                    my[b].entry = 0xffffffffu;
+                    my[b].count = 0;
+                } else {
+                    lane_bad = o.entry == 0xffffffffu || o.entry != prev_exit;
+                    if (b + 1u == n_blocks && o.exit != len_w) lane_bad = true;
+                }
+            }
+            if (__any(lane_bad)) { bad = true; break; }
+            const uint32_t inc = wave_incl_scan_dpp(b < n_blocks ? o.count : 0u);
+            if (b < n_blocks) my[b].base = run + inc - o.count;
+            run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        }
     }
     if (!bad && run != W) bad = true;
     // the last waveform may be shorter: its header has a tighter bound than the blocks checked
